@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""Benchmark of the un-projection hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+
+A step = one pass of the hot path (layout pass + fused un-projection kernel, through the C ABI) over one batch
+of synthetic input that is already resident in HBM.  Workload at N = 1: BASELINE.json's metric configuration --
+64^3 voxel grid, 256 channels, 4 views (H36M-like ring), 96x96 feature maps, batch 32, fp32, softmax aggregate,
+forward.  N > 1 is weak scaling: every rank owns its own batch of 32 (samples are independent, no data-path
+collective: SURVEY.md 8e); value = all ranks' voxel*views / max-over-ranks time.
+
+Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
+  roofline      algorithmic HBM bytes of the path (features + coords + proj + output, once each)
+                / the dominant kernel's average duration, measured with HIP events on the launch stream inside
+                the timed region; peak = 8 TB/s (MI355X_MICROARCH.md)
+  cpu_baseline  the reference's CPU algorithm (per-(b,v) F.grid_sample loop, oracle/reference_loop_torch.py)
+                timed on this box's host cores on a bounded sample (rank 0, N = 1 only)
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from multiviewhmr_amd import _capi, multiview  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--channels", type=int, default=256)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--feat", type=int, default=96)
+    ap.add_argument("--dtype", choices=("f32", "f16"), default="f32")
+    ap.add_argument("--method", default="softmax")
+    ap.add_argument("--variant", default="auto", choices=("auto", "gather", "brick"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    return ap.parse_args()
+
+
+# ------------------------------------------------------------------------------------------- synthetic inputs
+def ring_projections(batch, views, feat_hw, image_hw=(384, 384), seed=0):
+    """H36M-like ring: V cameras at azimuth 2*pi*k/V + 0.3, radius 4.5-5.5 m, height 1.5 m, looking at the origin,
+    z-up, 1000x1000 sensor, f = 1145 px; the reference's own bookkeeping (crop -> resize -> resize, Q3) gives P."""
+    rng = np.random.default_rng(seed)
+    P = np.empty((batch, views, 3, 4), np.float32)
+    for b in range(batch):
+        for v in range(views):
+            az = 2 * np.pi * v / views + 0.3
+            eye = np.array([np.cos(az), np.sin(az), 0.0]) * rng.uniform(4500.0, 5500.0) + np.array([0, 0, 1500.0])
+            fwd = -eye / np.linalg.norm(eye)
+            right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right)
+            R = np.stack([right, np.cross(fwd, right), fwd])
+            cam = multiview.Camera(R, -R @ eye, [[1145.0, 0, 512.0], [0, 1145.0, 512.0], [0, 0, 1.0]])
+            cam.update_after_crop((200, 200, 824, 824))
+            cam.update_after_resize((624, 624), (image_hw[1], image_hw[0]))
+            cam.update_after_resize(image_hw, feat_hw)
+            P[b, v] = cam.projection
+    return P
+
+
+def cuboid_volume(batch, S, side=2500.0, seed=0):
+    """aggregation.py:140-187 with theta = 0 (eval): origin-centred cuboid; the pivot is irrelevant at theta = 0."""
+    g = np.stack(np.meshgrid(np.arange(S), np.arange(S), np.arange(S), indexing="ij"), -1).astype(np.float32)
+    coords = (np.float32(-side / 2) + np.float32(side / (S - 1)) * g).astype(np.float32)
+    return np.broadcast_to(coords, (batch,) + coords.shape)
+
+
+def frustum_stats(P, coords, H, W):
+    pts = coords.reshape(-1, 3).astype(np.float64)
+    hom = np.concatenate([pts, np.ones((len(pts), 1))], 1)
+    inside, invalid = [], []
+    for Pv in P:
+        r = hom @ Pv.astype(np.float64).T
+        z = r[:, 2]
+        with np.errstate(all="ignore"):
+            ix = (r[:, 0] / z) / H * (W - 1)
+            iy = (r[:, 1] / z) / W * (H - 1)
+        inv = z <= 0
+        invalid.append(inv.mean())
+        inside.append(((ix > -1) & (ix < W) & (iy > -1) & (iy < H) & ~inv).mean())
+    return float(np.mean(inside)), float(np.mean(invalid))
+
+
+# ------------------------------------------------------------------------------------------- main
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    B, S, C, V, HW = a.batch, a.grid, a.channels, a.views, a.feat
+    N = S ** 3
+    tdt = torch.float32 if a.dtype == "f32" else torch.float16
+    esz = 4 if a.dtype == "f32" else 2
+
+    torch.manual_seed(rank)
+    feats = torch.randn(B, V, C, HW, HW, device=dev, dtype=torch.float32).to(tdt)
+    P_np = ring_projections(B, V, (HW, HW), seed=rank)
+    coords_np = cuboid_volume(1, S)
+    proj = torch.from_numpy(P_np).to(dev)
+    coords = torch.from_numpy(np.ascontiguousarray(coords_np)).to(dev).expand(B, S, S, S, 3).contiguous()
+    out = torch.empty(B, C, S, S, S, device=dev, dtype=tdt)
+
+    L = _capi.lib()
+    desc = _capi.Desc()
+    desc.abi_version = _capi.ABI_VERSION
+    desc.batch, desc.views, desc.channels, desc.feat_h, desc.feat_w = B, V, C, HW, HW
+    desc.vol_x = desc.vol_y = desc.vol_z = S
+    desc.method = _capi.AGG[a.method]
+    desc.feat_dtype = desc.out_dtype = _capi.F32 if a.dtype == "f32" else _capi.F16
+    desc.variant = _capi.VARIANT[a.variant]
+    # planar (reference-contract) input: the step runs the layout pass, then the fused kernel on its result
+    desc.feat_layout = _capi.LAYOUT_BVCHW
+    variant = L.mvhmr_unproject_selected_variant(ctypes.byref(desc))
+    two_kernels = variant == _capi.VARIANT["gather"]
+    vp = ctypes.c_void_p
+    stream = vp(torch.cuda.current_stream(dev).cuda_stream)
+    if two_kernels:
+        featT = torch.empty(L.mvhmr_channels_last_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
+        d_cl = _capi.Desc.from_buffer_copy(desc)
+        d_cl.feat_layout = _capi.LAYOUT_BVHWC
+        ws = None
+    else:
+        need = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc))
+        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * max(a.steps, 1))]
+
+    def step(i=None):
+        """one pass of the hot path; with i given, HIP events bracket the two kernels (same stream as the launches)"""
+        if two_kernels:
+            if i is not None: ev[3 * i].record()
+            _capi.check(L.mvhmr_features_to_channels_last(ctypes.byref(desc), vp(feats.data_ptr()), vp(featT.data_ptr()), stream))
+            if i is not None: ev[3 * i + 1].record()
+            _capi.check(L.mvhmr_unproject_forward(ctypes.byref(d_cl), vp(featT.data_ptr()), vp(proj.data_ptr()), vp(coords.data_ptr()),
+                                                  vp(out.data_ptr()), vp(0), 0, stream))
+            if i is not None: ev[3 * i + 2].record()
+        else:
+            if i is not None: ev[3 * i].record(); ev[3 * i + 1].record()
+            _capi.check(L.mvhmr_unproject_forward(ctypes.byref(desc), vp(feats.data_ptr()), vp(proj.data_ptr()), vp(coords.data_ptr()),
+                                                  vp(out.data_ptr()), vp(ws.data_ptr()), ws.numel(), stream))
+            if i is not None: ev[3 * i + 2].record()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_step = elapsed / a.steps * 1e3
+    k_layout = float(np.mean([ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(a.steps)]))
+    k_main = float(np.mean([ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(a.steps)]))
+
+    voxel_views = B * N * V * world
+    value = voxel_views / (elapsed / a.steps) / 1e6
+    # algorithmic bytes: every tensor of the path touched once; intermediates count zero
+    alg_bytes = B * V * C * HW * HW * esz + B * N * 3 * 4 + B * V * 12 * 4 + B * C * N * esz
+    achieved = alg_bytes / (k_main * 1e-3) / 1e9
+
+    result = {
+        "metric": "Mvoxel*views/s (64^3 grid, 256ch, 4 views) fwd; max-abs vs ref",
+        "value": round(value, 1), "unit": "Mvoxel*views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": "unprojection fwd %d^3 grid x %d ch x %d views, %dx%d maps, batch %d per GPU, %s, %s aggregate"
+                               % (S, C, V, HW, HW, B, a.dtype, a.method),
+                   "global_batch": B * world, "parallelism": "batch-sharded x%d, no data-path collective" % world,
+                   "kernel_variant": "brick" if variant == 2 else "gather", "input_layout": "BVCHW (reference contract)"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "k_fwd_brick" if variant == 2 else "k_fwd_gather", "kernel_ms": round(k_main, 4),
+                     "layout_pass_ms": round(k_layout, 4), "algorithmic_bytes": alg_bytes,
+                     "step_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+
+    if rank == 0:
+        traffic = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(traffic):
+            try:
+                tj = json.load(open(traffic))
+                if tj.get("workload_key") == "%d-%d-%d-%d-%d-%s" % (S, C, V, HW, B, a.dtype):
+                    result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                pass
+        inside, invalid = frustum_stats(P_np[0], coords_np[0], HW, HW)
+        result["config"]["in_frustum_fraction"] = round(inside, 4)
+        result["config"]["invalid_fraction"] = round(invalid, 4)
+        if not a.no_check:
+            from oracle import cport     # checker only: one sample against the CPU oracle
+            ref = cport.forward(feats[:1].float().cpu().numpy(), P_np[:1], np.ascontiguousarray(coords_np[:1]), a.method)
+            err = float(np.abs(out[:1].float().cpu().numpy() - ref).max())
+            result["max_abs_vs_ref"] = err
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle.reference_loop_torch import unprojection_cpu_loop
+            nb = min(a.cpu_sample_batch, B)
+            fc, pc = feats[:nb].float().cpu(), proj[:nb].cpu()
+            cc = torch.from_numpy(np.ascontiguousarray(coords_np)).expand(nb, S, S, S, 3).contiguous()
+            t1 = time.perf_counter()
+            unprojection_cpu_loop(fc, pc, cc, a.method)
+            dt = time.perf_counter() - t1
+            result["cpu_baseline"] = {"value": round(nb * N * V / dt / 1e6, 4), "unit": "Mvoxel*views/s",
+                                      "cores": torch.get_num_threads(), "kind": "port",
+                                      "sample": "%d of %d samples of the same workload, per-(b,v) F.grid_sample loop "
+                                                "(oracle/reference_loop_torch.py), %.1f s, host has %d cpus"
+                                                % (nb, B, dt, os.cpu_count())}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+/*
+ * mvhmr_unproject.h -- C ABI of the MI355X-native volumetric un-projection ("the hot path").
+ *
+ * The reference (yohanshin/MultiviewHMR) has no FFI layer: the boundary this library replaces is the
+ * plain Python function
+ *
+ *     unprojection(features, proj_matricies, coord_volumes, aggregation_method='softmax')
+ *         models/aggregation.py:20-87, sole call site models/aggregation.py:193
+ *
+ * and the autograd graph PyTorch builds through it (grid_sampler_2d_backward etc.).  Every entry
+ * point below takes plain device pointers, sizes and a HIP stream -- no torch types -- so that any
+ * host (ctypes, a torch C++ extension, a C++ trainer) can bind it; INTEGRATION.md shows the
+ * reference-side stub.  multiviewhmr_amd/_capi.py is the ctypes binding the Python host side uses.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers on the GPU that `stream` belongs to, except the descriptor;
+ *   - everything is stream-ordered: no allocation, no host synchronisation, safe to graph-capture;
+ *   - scratch memory comes from the caller (mvhmr_unproject_workspace_bytes), 256-byte aligned;
+ *   - tensors are dense row-major in the shapes given per function; voxel index
+ *     n = (x*vol_y + y)*vol_z + z, i.e. coord_volumes[b].reshape(-1, 3)  (aggregation.py:30);
+ *   - return value: MVHMR_OK or an mvhmr_status_t; mvhmr_last_error() gives the reason (thread-local).
+ */
+#ifndef MVHMR_UNPROJECT_H
+#define MVHMR_UNPROJECT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVHMR_ABI_VERSION 1
+
+typedef enum mvhmr_status_t {
+    MVHMR_OK = 0,
+    MVHMR_ERR_INVALID_ARGUMENT = 1, /* null pointer, non-positive size, unknown enum (-> ValueError/RuntimeError in Python) */
+    MVHMR_ERR_UNSUPPORTED = 2,      /* legal request this build has no kernel for */
+    MVHMR_ERR_WORKSPACE = 3,        /* workspace missing, too small or misaligned */
+    MVHMR_ERR_LAUNCH = 4            /* hipGetLastError() after a launch was not hipSuccess */
+} mvhmr_status_t;
+
+/* aggregation_method of models/aggregation.py:71-85 */
+typedef enum mvhmr_agg_t {
+    MVHMR_AGG_SOFTMAX = 0, /* sum_v x_v * softmax_v(x)_v  (aggregation.py:77-83) */
+    MVHMR_AGG_SUM = 1,     /* aggregation.py:71-72 */
+    MVHMR_AGG_MEAN = 2,    /* aggregation.py:73-74 : divides by V, masked views included */
+    MVHMR_AGG_MAX = 3      /* aggregation.py:75-76 */
+} mvhmr_agg_t;
+
+/* storage type of features / out / grad_out / grad_features.  Coordinates, projection matrices, tap
+ * weights, the cross-view softmax and all accumulation are always fp32.  The reference is fp32 only;
+ * MVHMR_F16 is this library's storage mode (SURVEY.md 8d "fp16 convention"). */
+typedef enum mvhmr_dtype_t { MVHMR_F32 = 0, MVHMR_F16 = 1 } mvhmr_dtype_t;
+
+/* memory layout of `features` (and of `grad_features`) */
+typedef enum mvhmr_layout_t {
+    MVHMR_LAYOUT_BVCHW = 0, /* (B,V,C,Hf,Wf) -- the reference's contract (aggregation.py:22-23, :191) */
+    MVHMR_LAYOUT_BVHWC = 1  /* (B,V,Hf,Wf,C) -- channels-last, what the kernels gather from; passing it
+                               skips the layout pass (e.g. a channels_last 1x1 conv upstream) */
+} mvhmr_layout_t;
+
+/* kernel selection; AUTO picks the fastest applicable one.  The others exist for tests and profiling. */
+typedef enum mvhmr_variant_t {
+    MVHMR_VARIANT_AUTO = 0,
+    MVHMR_VARIANT_GATHER = 1, /* channel-per-lane gather from L2, any shape */
+    MVHMR_VARIANT_BRICK = 2   /* voxel bricks with LDS-staged feature patches */
+} mvhmr_variant_t;
+
+typedef struct mvhmr_unproject_desc {
+    int32_t abi_version; /* MVHMR_ABI_VERSION */
+    int32_t batch;       /* B  = features.shape[0]              */
+    int32_t views;       /* V  = features.shape[1]   (1..16)    */
+    int32_t channels;    /* C  = features.shape[2]              */
+    int32_t feat_h;      /* Hf = features.shape[3]              */
+    int32_t feat_w;      /* Wf = features.shape[4]              */
+    int32_t vol_x;       /* coord_volumes.shape[1]              */
+    int32_t vol_y;       /* coord_volumes.shape[2]              */
+    int32_t vol_z;       /* coord_volumes.shape[3]              */
+    int32_t method;      /* mvhmr_agg_t                         */
+    int32_t feat_dtype;  /* mvhmr_dtype_t of features / grad_features */
+    int32_t out_dtype;   /* mvhmr_dtype_t of out / grad_out (the reference always returns fp32, aggregation.py:25) */
+    int32_t feat_layout; /* mvhmr_layout_t                      */
+    int32_t variant;     /* mvhmr_variant_t                     */
+} mvhmr_unproject_desc;
+
+/* Bytes of device scratch forward / backward need for this problem (0 is possible). */
+size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc);
+size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc);
+
+/*
+ * Forward: replaces unprojection() (models/aggregation.py:20-87).
+ *   features  (B,V,C,Hf,Wf) or (B,V,Hf,Wf,C) per desc->feat_layout, desc->feat_dtype   [read]
+ *   proj      (B,V,3,4) fp32   -- proj_matricies (aggregation.py:132-133)              [read]
+ *   coords    (B,X,Y,Z,3) fp32 -- coord_volumes  (aggregation.py:136,187)              [read]
+ *   out       (B,C,X,Y,Z) desc->out_dtype, every element is written                     [write]
+ */
+int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *features, const float *proj,
+                            const float *coords, void *out, void *workspace, size_t workspace_bytes,
+                            void *hip_stream);
+
+/*
+ * Backward w.r.t. features: replaces autograd through the reference graph (CopySlices, softmax/mul/sum,
+ * masked fill, grid_sampler_2d_backward per (b, v)); proj and coords never need gradients
+ * (they are built from numpy / arange, aggregation.py:132-187).
+ *   grad_out       (B,C,X,Y,Z) desc->out_dtype                                          [read]
+ *   grad_features  same shape/layout/dtype as features, every element is written        [write]
+ * Scatter-adds use fp32 float atomics, so low-order bits can differ from run to run.
+ */
+int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_out, const void *features,
+                             const float *proj, const float *coords, void *grad_features, void *workspace,
+                             size_t workspace_bytes, void *hip_stream);
+
+/*
+ * Layout pass on its own: features (B,V,C,Hf,Wf) -> dst (B,V,Hf,Wf,C4) in desc->feat_dtype, C4 = C rounded up
+ * to a multiple of 4 (padding channels are zero).  mvhmr_unproject_forward runs this internally into its
+ * workspace when desc->feat_layout is MVHMR_LAYOUT_BVCHW; callers that keep the channels-last copy (or time
+ * the two kernels separately) call it themselves and then pass MVHMR_LAYOUT_BVHWC.  dst needs
+ * mvhmr_channels_last_bytes(desc) bytes.
+ */
+size_t mvhmr_channels_last_bytes(const mvhmr_unproject_desc *desc);
+int mvhmr_features_to_channels_last(const mvhmr_unproject_desc *desc, const void *features, void *dst,
+                                    void *hip_stream);
+
+/*
+ * Caller-side helper of VolumeGenerator.forward (models/aggregation.py:138-187): fills
+ * coords (B,S,S,S,3) fp32 with the cuboid grid `position + side/(S-1) * (i,j,k)` rotated by
+ * rot[b] (3x3 row-major fp32, utils/volumetric.py:87-114) about center[b] (3 fp32):
+ *     coords = rot @ (grid - center) + center
+ * position is the cuboid corner, sides its edge lengths (3 doubles each, HOST memory, as the reference
+ * holds them in float64 numpy, aggregation.py:143-144); rot / center / coords are device pointers.
+ */
+int mvhmr_build_coord_volumes(float *coords, const float *rot, const float *center, int32_t batch,
+                              int32_t volume_size, const double position[3], const double sides[3],
+                              void *hip_stream);
+
+/* Which kernel AUTO would run for this problem (an mvhmr_variant_t), for logs and tests. */
+int mvhmr_unproject_selected_variant(const mvhmr_unproject_desc *desc);
+
+int mvhmr_abi_version(void);
+const char *mvhmr_status_string(int status);
+const char *mvhmr_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVHMR_UNPROJECT_H */

@@ -1,0 +1,267 @@
+"""Drop-in for the reference's models/aggregation.py on MI355X.
+
+    unprojection(features, proj_matricies, coord_volumes, aggregation_method='softmax')   aggregation.py:20-87
+    VolumeGenerator(...).forward(features, proj_matricies, batch, use_gt=True)            aggregation.py:90-195
+    build_volume_generator(cfg)                                                           aggregation.py:198-208
+
+Same names, argument meaning, return shapes/dtypes, state-dict keys and quirks (SURVEY.md section 8a,
+Q1-Q6).  What differs is HOW: the b x v Python loop with ~20 ATen launches per iteration and the
+(V,C,X,Y,Z) intermediates is one fused HIP kernel launch behind the C ABI of include/mvhmr_unproject.h
+(forward), and one more for the gradient w.r.t. `features` (backward), wrapped in a
+torch.autograd.Function.  There is no CPU / eager fallback: the call raises if the tensors are not on
+a HIP device or the library is not built.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _capi, multiview, volumetric
+
+_METHODS = ("softmax", "sum", "mean", "max")            # aggregation.py:71-85
+_TYPE_MSG = "Works only with numpy arrays and PyTorch tensors."
+
+
+# --------------------------------------------------------------------------------------- C-ABI plumbing
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _workspace(nbytes, device):
+    if nbytes == 0:
+        return None, ctypes.c_void_p(0)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=device)   # caching allocator: 512-B aligned, stream-ordered
+    return ws, _ptr(ws)
+
+
+def _is_channels_last5(features):
+    """True when the (B,V,C,H,W) tensor is physically (B,V,H,W,C) -- e.g. a channels_last conv output."""
+    return features.dim() == 5 and features.shape[2] > 1 and features.permute(0, 1, 3, 4, 2).is_contiguous()
+
+
+def _dtype_code(dt):
+    if dt == torch.float32:
+        return _capi.F32
+    if dt == torch.float16:
+        return _capi.F16
+    raise RuntimeError("unprojection: features / volume must be float32 or float16, got %s" % dt)
+
+
+def _make_desc(features, coord_volumes, method, out_dtype, layout, variant):
+    B, V, C, Hf, Wf = features.shape
+    d = _capi.Desc()
+    d.abi_version = _capi.ABI_VERSION
+    d.batch, d.views, d.channels, d.feat_h, d.feat_w = B, V, C, Hf, Wf
+    d.vol_x, d.vol_y, d.vol_z = (int(s) for s in coord_volumes.shape[1:4])
+    d.method = method
+    d.feat_dtype = _dtype_code(features.dtype)
+    d.out_dtype = _dtype_code(out_dtype)
+    d.feat_layout = layout
+    d.variant = variant
+    return d
+
+
+class _Unprojection(torch.autograd.Function):
+    """forward -> mvhmr_unproject_forward, backward -> mvhmr_unproject_backward (grad w.r.t. features only:
+    proj_matricies and coord_volumes come from numpy / arange in the caller and never require grad)."""
+
+    @staticmethod
+    def forward(ctx, features, proj, coords, method, out_dtype, variant):
+        L = _capi.lib()
+        layout = _capi.LAYOUT_BVHWC if _is_channels_last5(features) else _capi.LAYOUT_BVCHW
+        if layout == _capi.LAYOUT_BVCHW:
+            features = features.contiguous()
+        desc = _make_desc(features, coords, method, out_dtype, layout, variant)
+        B, C = features.shape[0], features.shape[2]
+        with torch.cuda.device(features.device):
+            out = torch.empty((B, C) + tuple(coords.shape[1:4]), dtype=out_dtype, device=features.device)
+            ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), features.device)
+            _capi.check(L.mvhmr_unproject_forward(ctypes.byref(desc), _ptr(features), _ptr(proj), _ptr(coords), _ptr(out),
+                                                  wsp, 0 if ws is None else ws.numel(), _stream(features.device)))
+        ctx.save_for_backward(features, proj, coords)
+        ctx.desc = desc
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, proj, coords = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None, None
+        L = _capi.lib()
+        desc = ctx.desc
+        grad_out = grad_out.contiguous()
+        with torch.cuda.device(features.device):
+            grad_features = torch.empty_like(features)           # keeps the (possibly channels-last) strides
+            ws, wsp = _workspace(L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc)), features.device)
+            _capi.check(L.mvhmr_unproject_backward(ctypes.byref(desc), _ptr(grad_out), _ptr(features), _ptr(proj), _ptr(coords),
+                                                   _ptr(grad_features), wsp, 0 if ws is None else ws.numel(),
+                                                   _stream(features.device)))
+        return grad_features, None, None, None, None, None
+
+
+def unprojection(features, proj_matricies, coord_volumes, aggregation_method='softmax', *, out_dtype=None,
+                 variant='auto'):
+    """Fused project -> bilinear-sample -> cross-view aggregate (reference: models/aggregation.py:20-87).
+
+    features        (B, V, C, Hf, Wf) float32 (or float16, this package's storage mode) on a HIP device;
+                    a channels-last-strided tensor (physically (B,V,Hf,Wf,C)) is consumed without a layout pass
+    proj_matricies  (B, V, 3, 4)  -- feature-resolution projection matrices
+    coord_volumes   (B, X, Y, Z, 3) -- voxel centres in world units
+    aggregation_method  'softmax' | 'sum' | 'mean' | 'max'; anything else -> ValueError (aggregation.py:85)
+    returns         a new (B, C, X, Y, Z) tensor on features.device, float32 like the reference (aggregation.py:25)
+                    unless out_dtype is given (float16 features default to a float16 volume)
+
+    `out_dtype` and `variant` ('auto' | 'gather' | 'brick') are keyword-only extensions.
+    """
+    for t in (features, proj_matricies, coord_volumes):
+        if not torch.is_tensor(t):
+            raise TypeError(_TYPE_MSG)                       # utils/multiview.py:110
+    if aggregation_method not in _METHODS:
+        raise ValueError("Unknown aggregation_method: {}".format(aggregation_method))
+    if variant not in _capi.VARIANT:
+        raise ValueError("Unknown kernel variant: {}".format(variant))
+    if features.dim() != 5:
+        raise RuntimeError("unprojection: features must be (B, V, C, Hf, Wf), got %s" % (tuple(features.shape),))
+    B, V = features.shape[:2]
+    if tuple(proj_matricies.shape) != (B, V, 3, 4):
+        raise RuntimeError("unprojection: proj_matricies must be (%d, %d, 3, 4), got %s" % (B, V, tuple(proj_matricies.shape)))
+    if coord_volumes.dim() != 5 or coord_volumes.shape[0] != B or coord_volumes.shape[4] != 3:
+        raise RuntimeError("unprojection: coord_volumes must be (%d, X, Y, Z, 3), got %s" % (B, tuple(coord_volumes.shape)))
+    if not features.is_cuda:
+        raise RuntimeError("unprojection: features live on %s; this implementation runs only on a HIP device "
+                           "(MI355X) and has no CPU path" % features.device)
+    if proj_matricies.device != features.device or coord_volumes.device != features.device:
+        raise RuntimeError("unprojection: expected all tensors on %s, got proj_matricies on %s and coord_volumes on %s"
+                           % (features.device, proj_matricies.device, coord_volumes.device))
+    if out_dtype is None:
+        out_dtype = torch.float16 if features.dtype == torch.float16 else torch.float32
+    proj = proj_matricies.detach().to(torch.float32).contiguous()
+    coords = coord_volumes.detach().to(torch.float32).contiguous()
+    return _Unprojection.apply(features, proj, coords, _capi.AGG[aggregation_method], out_dtype, _capi.VARIANT[variant])
+
+
+# --------------------------------------------------------------------------------------- caller side
+def feature_level_projections(cameras, images_shape, features_shape):
+    """(B, V, 3, 4) float32 numpy: projection matrices at feature-map resolution.
+
+    Reference: deep-copies every Camera, calls update_after_resize(images_shape, features_shape) and reads
+    .projection (aggregation.py:127-133, utils/multiview.py:33-52) -- including quirk Q3 (features_shape
+    = (Hf, Wf) is unpacked as (new_width, new_height)).  Here the same float64 arithmetic runs on copies
+    of K only; `cameras` is list[V] of list[B] and is not modified.
+    """
+    height, width = images_shape
+    new_width, new_height = features_shape
+    sx, sy = new_width / width, new_height / height
+    V, B = len(cameras), len(cameras[0])
+    out = np.empty((B, V, 3, 4), dtype=np.float32)
+    for v in range(V):
+        for b in range(B):
+            cam = cameras[v][b]
+            K = np.array(cam.K, dtype=np.float64, copy=True)
+            K[0, 0], K[1, 1] = K[0, 0] * sx, K[1, 1] * sy
+            K[0, 2], K[1, 2] = K[0, 2] * sx, K[1, 2] * sy
+            out[b, v] = K.dot(np.hstack([cam.R, cam.t]))
+    return out
+
+
+class VolumeGenerator(nn.Module):
+    """1x1 conv on the per-view feature maps + un-projection into a voxel volume (aggregation.py:90-195)."""
+
+    def __init__(self, volume_size=64, input_channels=256, output_channels=32, cuboid_side=2500.0,
+                 aggregation_method='softmax', use_triangulation=False, kind='mpii', device='cuda',
+                 dataset='human36m', **kwargs):
+        # **kwargs swallows unknown keywords exactly like the reference (quirk Q5: build_volume_generator
+        # passes volume_aggregation_method=, so aggregation_method keeps its default)
+        super().__init__()
+        self.volume_size = volume_size
+        self.cuboid_side = cuboid_side
+        self.aggregation_method = aggregation_method
+        self.process_feature = nn.Sequential(nn.Conv2d(input_channels, output_channels, 1))   # keys process_feature.0.*
+        self.use_triangulation = use_triangulation
+        self.kind = kind
+        self.dataset = dataset
+        self.to(device)
+
+    # -- geometry the reference builds inside forward(); split out so it can be checked without a GPU
+    def cuboid(self):
+        sides = np.array([self.cuboid_side, self.cuboid_side, self.cuboid_side])
+        position = np.array([0, 0, 0]) - sides / 2          # quirk Q4: centred on the world origin (:140-144)
+        return volumetric.Cuboid3D(position, sides)
+
+    def rotation_axis(self):
+        if self.kind == "coco":
+            return [0, 1, 0]
+        if self.kind == "mpii":
+            return [0, 0, 1]
+        raise ValueError("Unknown kind: {}".format(self.kind))  # the reference fails with UnboundLocalError here
+
+    def volume_pose(self, batch, proj_matricies_org, images_shape):
+        """Per-sample rotation (B,3,3) and pivot (B,3), float32 numpy/tensor (aggregation.py:163-181).
+
+        Training draws theta ~ U(0, 2 pi) from the GLOBAL numpy stream, one draw per sample in order
+        (quirk Q6); eval uses theta = 0.  The pivot is keypoints_3d[b][6, :3], or the DLT-triangulated
+        image centre when use_triangulation is set."""
+        batch_size = proj_matricies_org.shape[0]
+        axis = self.rotation_axis()
+        rots = np.empty((batch_size, 3, 3), dtype=np.float32)
+        centers = []
+        for b in range(batch_size):
+            theta = np.random.uniform(0.0, 2 * np.pi) if self.training else 0.0
+            rots[b] = volumetric.get_rotation_matrix(axis, theta)
+            if self.use_triangulation:
+                n_views = proj_matricies_org.shape[1]
+                images_center = (torch.tensor(images_shape) / 2).expand(n_views, 2).to(proj_matricies_org.device)
+                center = multiview.triangulate_point_from_multiple_views_linear_torch(proj_matricies_org[b], images_center)
+                centers.append(center.detach().to(torch.float32).cpu())
+            else:
+                centers.append(torch.from_numpy(np.asarray(batch['keypoints_3d'][b][6, :3])).type(torch.float))
+        return torch.from_numpy(rots), torch.stack(centers)
+
+    def coord_volumes(self, rots, centers, device):
+        """(B,S,S,S,3) float32 on `device`: rot @ (grid - center) + center, built by one kernel
+        (mvhmr_build_coord_volumes) instead of B x (meshgrid + 3 strided writes + mm) (aggregation.py:138-187)."""
+        L = _capi.lib()
+        B, S = rots.shape[0], self.volume_size
+        cub = self.cuboid()
+        rots = rots.to(device=device, dtype=torch.float32).contiguous()
+        centers = centers.to(device=device, dtype=torch.float32).contiguous()
+        with torch.cuda.device(device):
+            coords = torch.empty(B, S, S, S, 3, dtype=torch.float32, device=device)
+            pos = (ctypes.c_double * 3)(*[float(x) for x in cub.position])
+            sides = (ctypes.c_double * 3)(*[float(x) for x in cub.sides])
+            _capi.check(L.mvhmr_build_coord_volumes(_ptr(coords), _ptr(rots), _ptr(centers), B, S, pos, sides, _stream(device)))
+        return coords
+
+    def forward(self, features, proj_matricies, batch, use_gt=True):
+        features_shape = tuple(features.shape[-2:])
+        images_shape = tuple(batch['images'].shape[2:-1])
+        batch_size, n_views = batch['images'].shape[:2]
+        device = features.device
+
+        proj_org = proj_matricies                                           # only read (reference clones, :124)
+        proj = torch.from_numpy(feature_level_projections(batch['cameras'], images_shape, features_shape)).to(device)
+        rots, centers = self.volume_pose(batch, proj_org, images_shape)
+        coord_volumes = self.coord_volumes(rots, centers, device)
+
+        features = features.view(-1, *features.shape[2:])
+        features = self.process_feature(features)
+        features = features.view(batch_size, n_views, *features.shape[1:])
+        return unprojection(features, proj, coord_volumes, aggregation_method=self.aggregation_method)
+
+
+def build_volume_generator(cfg):
+    """cfg is the reference's yacs tree (cfg/defaults.py:18-30,89-90); same wiring as aggregation.py:198-208."""
+    input_channels = cfg.MODEL.BACKBONE.DECONV_FILTERS[-1] if cfg.MODEL.BACKBONE.DECONV_LAYERS != 0 else 2048
+    return VolumeGenerator(volume_size=cfg.MODEL.AGGREGATION.VOLUME_SIZE,
+                           input_channels=input_channels,
+                           output_channels=cfg.MODEL.AGGREGATION.OUTPUT_CHANNELS,
+                           cuboid_side=cfg.MODEL.AGGREGATION.CUBOID_SIDE,
+                           use_triangulation=cfg.MODEL.AGGREGATION.USE_TRIANGULATION,
+                           kind=cfg.DATASET.KIND,
+                           dataset=cfg.DATASET.TYPE,
+                           volume_aggregation_method=cfg.MODEL.AGGREGATION.METHOD)

@@ -1,0 +1,225 @@
+// extern "C" surface of libmvhmr_unproject.so -- see include/mvhmr_unproject.h for the contract and the
+// reference interface (models/aggregation.py:20-87) each entry point replaces.
+#include "mvhmr_unproject.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "device_common.h"
+#include "kernels.h"
+
+using namespace mvhmr;
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int status, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+constexpr size_t kAlign = 256;
+size_t align_up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+int check_desc(const mvhmr_unproject_desc *d, Problem *p)
+{
+    if (!d) return fail(MVHMR_ERR_INVALID_ARGUMENT, "descriptor is null");
+    if (d->abi_version != MVHMR_ABI_VERSION)
+        return fail(MVHMR_ERR_INVALID_ARGUMENT, "descriptor abi_version %d, library speaks %d", d->abi_version, MVHMR_ABI_VERSION);
+    if (d->batch < 1 || d->views < 1 || d->channels < 1 || d->feat_h < 1 || d->feat_w < 1 || d->vol_x < 1 || d->vol_y < 1 || d->vol_z < 1)
+        return fail(MVHMR_ERR_INVALID_ARGUMENT, "every dimension must be >= 1 (B=%d V=%d C=%d Hf=%d Wf=%d vol=%dx%dx%d)", d->batch, d->views,
+                    d->channels, d->feat_h, d->feat_w, d->vol_x, d->vol_y, d->vol_z);
+    if (d->method < MVHMR_AGG_SOFTMAX || d->method > MVHMR_AGG_MAX)
+        return fail(MVHMR_ERR_INVALID_ARGUMENT, "Unknown aggregation_method: %d", d->method);
+    if (d->feat_dtype < 0 || d->feat_dtype > MVHMR_F16 || d->out_dtype < 0 || d->out_dtype > MVHMR_F16)
+        return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown dtype (feat %d, out %d)", d->feat_dtype, d->out_dtype);
+    if (d->feat_layout < 0 || d->feat_layout > MVHMR_LAYOUT_BVHWC) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown feature layout %d", d->feat_layout);
+    if (d->variant < 0 || d->variant > MVHMR_VARIANT_BRICK) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", d->variant);
+    if (d->views > kMaxViews) return fail(MVHMR_ERR_UNSUPPORTED, "at most %d views are supported (got %d)", kMaxViews, d->views);
+    if (d->feat_dtype == MVHMR_F32 && d->out_dtype == MVHMR_F16)
+        return fail(MVHMR_ERR_UNSUPPORTED, "fp32 features with an fp16 volume is not a supported storage mode");
+    p->B = d->batch; p->V = d->views; p->C = d->channels; p->H = d->feat_h; p->W = d->feat_w;
+    p->X = d->vol_x; p->Y = d->vol_y; p->Z = d->vol_z;
+    p->N = (long long)d->vol_x * d->vol_y * d->vol_z;
+    p->C4 = (d->channels + 3) / 4 * 4;
+    p->method = d->method;
+    p->feat_f16 = d->feat_dtype == MVHMR_F16;
+    p->out_f16 = d->out_dtype == MVHMR_F16;
+    if ((long long)p->H * p->W * p->C4 >= (1ll << 31))
+        return fail(MVHMR_ERR_UNSUPPORTED, "one feature map (Hf*Wf*C = %lld elements) exceeds 32-bit tap offsets", (long long)p->H * p->W * p->C4);
+    if (d->feat_layout == MVHMR_LAYOUT_BVHWC && p->C4 != p->C)
+        return fail(MVHMR_ERR_UNSUPPORTED, "channels-last features need C %% 4 == 0 (C = %d)", p->C);
+    return MVHMR_OK;
+}
+
+size_t feat_elem(const Problem &p) { return p.feat_f16 ? 2 : 4; }
+size_t featT_bytes(const Problem &p) { return align_up((size_t)p.B * p.V * p.H * p.W * p.C4 * feat_elem(p)); }
+size_t gradT_bytes(const Problem &p) { return align_up((size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float)); }
+
+int pick_variant(const mvhmr_unproject_desc *d, const Problem &p)
+{
+    if (d->variant == MVHMR_VARIANT_GATHER) return MVHMR_VARIANT_GATHER;
+    return brick_supported(p) ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
+}
+
+// the gradient can be accumulated straight into grad_features when that already is fp32 channels-last
+bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->feat_layout == MVHMR_LAYOUT_BVHWC && !p.feat_f16; }
+
+int check_ws(void *ws, size_t have, size_t need)
+{
+    if (need == 0) return MVHMR_OK;
+    if (!ws) return fail(MVHMR_ERR_WORKSPACE, "workspace is null but %zu bytes are required", need);
+    if (have < need) return fail(MVHMR_ERR_WORKSPACE, "workspace has %zu bytes, %zu are required", have, need);
+    if (reinterpret_cast<uintptr_t>(ws) % kAlign) return fail(MVHMR_ERR_WORKSPACE, "workspace must be %zu-byte aligned", kAlign);
+    return MVHMR_OK;
+}
+
+int launched(hipError_t e, const char *what)
+{
+    if (e == hipSuccess) return MVHMR_OK;
+    if (e == hipErrorNotSupported) return fail(MVHMR_ERR_UNSUPPORTED, "%s: no kernel for this dtype/shape combination", what);
+    return fail(MVHMR_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+}
+
+}  // namespace
+
+extern "C" {
+
+int mvhmr_abi_version(void) { return MVHMR_ABI_VERSION; }
+
+const char *mvhmr_last_error(void) { return g_err; }
+
+const char *mvhmr_status_string(int status)
+{
+    switch (status) {
+    case MVHMR_OK: return "ok";
+    case MVHMR_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case MVHMR_ERR_UNSUPPORTED: return "unsupported";
+    case MVHMR_ERR_WORKSPACE: return "workspace";
+    case MVHMR_ERR_LAUNCH: return "kernel launch failed";
+    default: return "unknown status";
+    }
+}
+
+int mvhmr_unproject_selected_variant(const mvhmr_unproject_desc *desc)
+{
+    Problem p;
+    if (check_desc(desc, &p) != MVHMR_OK) return -1;
+    if (desc->variant == MVHMR_VARIANT_BRICK && !brick_supported(p)) return -1;
+    return pick_variant(desc, p);
+}
+
+size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc)
+{
+    Problem p;
+    if (check_desc(desc, &p) != MVHMR_OK) return 0;
+    if (pick_variant(desc, p) == MVHMR_VARIANT_BRICK) return brick_workspace_bytes(p);
+    return desc->feat_layout == MVHMR_LAYOUT_BVCHW ? featT_bytes(p) : 0;
+}
+
+size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc)
+{
+    Problem p;
+    if (check_desc(desc, &p) != MVHMR_OK) return 0;
+    size_t need = desc->feat_layout == MVHMR_LAYOUT_BVCHW ? featT_bytes(p) : 0;
+    if (!grad_in_place(desc, p)) need += gradT_bytes(p);
+    return need;
+}
+
+int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *features, const float *proj, const float *coords,
+                            void *out, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    Problem p;
+    int rc = check_desc(desc, &p);
+    if (rc != MVHMR_OK) return rc;
+    if (!features || !proj || !coords || !out) return fail(MVHMR_ERR_INVALID_ARGUMENT, "features / proj / coords / out must be non-null");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const int variant = pick_variant(desc, p);
+    if (desc->variant == MVHMR_VARIANT_BRICK && variant != MVHMR_VARIANT_BRICK)
+        return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape");
+    rc = check_ws(workspace, workspace_bytes, mvhmr_unproject_forward_workspace_bytes(desc));
+    if (rc != MVHMR_OK) return rc;
+
+    if (variant == MVHMR_VARIANT_BRICK)
+        return launched(launch_fwd_brick(features, desc->feat_layout == MVHMR_LAYOUT_BVHWC, proj, coords, out, workspace, p, s), "brick forward");
+
+    const void *featT = features;
+    if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) {
+        rc = launched(launch_to_channels_last(features, workspace, p, s), "layout pass");
+        if (rc != MVHMR_OK) return rc;
+        featT = workspace;
+    }
+    return launched(launch_fwd_gather(featT, proj, coords, out, p, s), "gather forward");
+}
+
+int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_out, const void *features, const float *proj,
+                             const float *coords, void *grad_features, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    Problem p;
+    int rc = check_desc(desc, &p);
+    if (rc != MVHMR_OK) return rc;
+    if (!grad_out || !features || !proj || !coords || !grad_features)
+        return fail(MVHMR_ERR_INVALID_ARGUMENT, "grad_out / features / proj / coords / grad_features must be non-null");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    rc = check_ws(workspace, workspace_bytes, mvhmr_unproject_backward_workspace_bytes(desc));
+    if (rc != MVHMR_OK) return rc;
+
+    unsigned char *ws = static_cast<unsigned char *>(workspace);
+    const void *featT = features;
+    if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) {
+        rc = launched(launch_to_channels_last(features, ws, p, s), "layout pass");
+        if (rc != MVHMR_OK) return rc;
+        featT = ws;
+        ws += featT_bytes(p);
+    }
+    const bool in_place = grad_in_place(desc, p);
+    float *gradT = in_place ? static_cast<float *>(grad_features) : reinterpret_cast<float *>(ws);
+    const size_t gbytes = (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float);
+    hipError_t e = hipMemsetAsync(gradT, 0, gbytes, s);
+    if (e != hipSuccess) return launched(e, "gradient clear");
+    rc = launched(launch_bwd_gather(grad_out, featT, proj, coords, gradT, p, s), "gather backward");
+    if (rc != MVHMR_OK || in_place) return rc;
+    if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) return launched(launch_grad_to_planar(gradT, grad_features, p, s), "gradient layout pass");
+    return launched(launch_grad_cast(gradT, grad_features, p, s), "gradient cast");
+}
+
+size_t mvhmr_channels_last_bytes(const mvhmr_unproject_desc *desc)
+{
+    Problem p;
+    mvhmr_unproject_desc d;
+    if (!desc) return 0;
+    d = *desc;
+    d.feat_layout = MVHMR_LAYOUT_BVCHW;
+    if (check_desc(&d, &p) != MVHMR_OK) return 0;
+    return featT_bytes(p);
+}
+
+int mvhmr_features_to_channels_last(const mvhmr_unproject_desc *desc, const void *features, void *dst, void *hip_stream)
+{
+    Problem p;
+    mvhmr_unproject_desc d;
+    if (!desc) return fail(MVHMR_ERR_INVALID_ARGUMENT, "descriptor is null");
+    d = *desc;
+    d.feat_layout = MVHMR_LAYOUT_BVCHW;
+    int rc = check_desc(&d, &p);
+    if (rc != MVHMR_OK) return rc;
+    if (!features || !dst) return fail(MVHMR_ERR_INVALID_ARGUMENT, "features / dst must be non-null");
+    return launched(launch_to_channels_last(features, dst, p, static_cast<hipStream_t>(hip_stream)), "layout pass");
+}
+
+int mvhmr_build_coord_volumes(float *coords, const float *rot, const float *center, int32_t batch, int32_t volume_size,
+                              const double position[3], const double sides[3], void *hip_stream)
+{
+    if (!coords || !rot || !center || !position || !sides) return fail(MVHMR_ERR_INVALID_ARGUMENT, "null pointer");
+    if (batch < 1 || volume_size < 1) return fail(MVHMR_ERR_INVALID_ARGUMENT, "batch and volume_size must be >= 1");
+    return launched(launch_build_coords(coords, rot, center, batch, volume_size, position, sides, static_cast<hipStream_t>(hip_stream)),
+                    "coord volume build");
+}
+
+}  // extern "C"

@@ -1,0 +1,213 @@
+// Device-side building blocks shared by every un-projection kernel (gfx950 / CDNA4 only).
+//
+// Arithmetic contract.  The per-view sample must agree with the reference's CPU path
+// (models/aggregation.py:38-62 -> ATen sgemm + grid_sampler_2d) as closely as fp32 allows, because
+// the projection is ill-conditioned (mm-scale coordinates times ~1e2 px/m focal lengths): a different
+// rounding ORDER alone moves the result by ~4e-5 against a 1e-4 bar.  The orders below were pinned
+// bit-for-bit against torch 2.10 in the build container (see oracle/unproject_oracle.c):
+//   projection   r_k = fma(P_k3, 1, fma(P_k2, X2, fma(P_k1, X1, P_k0 * X0)))           multiview.py:105
+//   divide       IEEE (u = a / z), then 2 * (u / Hf - 0.5), ((g + 1) / 2) * (size - 1)  aggregation.py:49-50
+//   bilinear     fma(se_v, se, fma(sw_v, sw, fma(ne_v, ne, nw_v * nw)))                 grid_sampler_2d
+// Everything here is compiled with -ffp-contract=off; fused operations are spelled out.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+namespace mvhmr {
+
+enum : int { AGG_SOFTMAX = 0, AGG_SUM = 1, AGG_MEAN = 2, AGG_MAX = 3 };
+
+constexpr int kWave = 64;       // CDNA wavefront
+constexpr int kMaxViews = 16;   // per-voxel view records kept in LDS / registers
+
+// One voxel seen by one camera: pixel coordinates of the nw tap and the four bilinear weights.
+// A tap outside the map keeps weight 0 and a clamped (always readable) pixel, which is what
+// zero padding means for a linear sampler (aggregation.py:55-58); z <= 0 zeroes all four
+// (aggregation.py:42,62).  `any` is 0 when the whole sample is exactly zero.
+struct Taps {
+    int x0, y0, x1, y1;          // clamped to [0, W-1] / [0, H-1]
+    float w00, w01, w10, w11;    // (y0,x0) (y0,x1) (y1,x0) (y1,x1) = nw, ne, sw, se
+    int any;
+};
+
+__device__ __forceinline__ Taps make_taps(const float *__restrict__ P, float X0, float X1, float X2, int H, int W)
+{
+    const float a = __fmaf_rn(P[3], 1.f, __fmaf_rn(P[2], X2, __fmaf_rn(P[1], X1, __fmul_rn(P[0], X0))));
+    const float b = __fmaf_rn(P[7], 1.f, __fmaf_rn(P[6], X2, __fmaf_rn(P[5], X1, __fmul_rn(P[4], X0))));
+    const float z = __fmaf_rn(P[11], 1.f, __fmaf_rn(P[10], X2, __fmaf_rn(P[9], X1, __fmul_rn(P[8], X0))));
+    Taps t;
+    t.x0 = t.y0 = t.x1 = t.y1 = 0;
+    t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+    t.any = 0;
+    if (!(z > 0.f)) return t;                        // z <= 0 (or NaN): sample is exactly 0
+    const float u = __fdiv_rn(a, z), v = __fdiv_rn(b, z);
+    // quirk Q1: x is normalised by feature_shape[0] = Hf, y by feature_shape[1] = Wf
+    const float gx = __fmul_rn(2.f, __fsub_rn(__fdiv_rn(u, (float)H), 0.5f));
+    const float gy = __fmul_rn(2.f, __fsub_rn(__fdiv_rn(v, (float)W), 0.5f));
+    const float ix = __fmul_rn(__fmul_rn(__fadd_rn(gx, 1.f), 0.5f), (float)(W - 1));   // (g+1)/2 is exact either way
+    const float iy = __fmul_rn(__fmul_rn(__fadd_rn(gy, 1.f), 0.5f), (float)(H - 1));
+    if (!(ix > -1.f && ix < (float)W && iy > -1.f && iy < (float)H)) return t;        // all four taps outside
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = __fsub_rn(ix, fx0), wx0 = __fsub_rn(__fadd_rn(fx0, 1.f), ix);
+    const float wy1 = __fsub_rn(iy, fy0), wy0 = __fsub_rn(__fadd_rn(fy0, 1.f), iy);
+    const bool xin0 = x0 >= 0, xin1 = x1 <= W - 1, yin0 = y0 >= 0, yin1 = y1 <= H - 1;
+    t.w00 = (xin0 && yin0) ? __fmul_rn(wx0, wy0) : 0.f;
+    t.w01 = (xin1 && yin0) ? __fmul_rn(wx1, wy0) : 0.f;
+    t.w10 = (xin0 && yin1) ? __fmul_rn(wx0, wy1) : 0.f;
+    t.w11 = (xin1 && yin1) ? __fmul_rn(wx1, wy1) : 0.f;
+    t.x0 = xin0 ? x0 : 0;
+    t.y0 = yin0 ? y0 : 0;
+    t.x1 = xin1 ? x1 : W - 1;
+    t.y1 = yin1 ? y1 : H - 1;
+    t.any = 1;
+    return t;
+}
+
+__device__ __forceinline__ float bilerp(float v00, float v01, float v10, float v11, float w00, float w01, float w10, float w11)
+{
+    return __fmaf_rn(v11, w11, __fmaf_rn(v10, w10, __fmaf_rn(v01, w01, __fmul_rn(v00, w00))));
+}
+
+// ---------------------------------------------------------------- cross-view aggregate (aggregation.py:71-85)
+// s[0..V) are the per-view samples of one (voxel, channel); returns the aggregated value.
+template <int METHOD, int V>
+__device__ __forceinline__ float aggregate(const float (&s)[V])
+{
+    if constexpr (METHOD == AGG_SUM || METHOD == AGG_MEAN) {
+        float r = s[0];
+#pragma unroll
+        for (int v = 1; v < V; ++v) r = __fadd_rn(r, s[v]);
+        return METHOD == AGG_MEAN ? __fdiv_rn(r, (float)V) : r;
+    } else if constexpr (METHOD == AGG_MAX) {
+        float r = s[0];
+#pragma unroll
+        for (int v = 1; v < V; ++v) r = fmaxf(r, s[v]);
+        return r;
+    } else {
+        float m = s[0];
+#pragma unroll
+        for (int v = 1; v < V; ++v) m = fmaxf(m, s[v]);
+        // e_v = exp(s_v - m) as exp2((s_v - m) * log2e): one fma + v_exp_f32 per view
+        const float nm = -m * 1.4426950408889634f;
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float e = __builtin_amdgcn_exp2f(fmaf(s[v], 1.4426950408889634f, nm));
+            den += e;
+            num = fmaf(e, s[v], num);
+        }
+        return num * __builtin_amdgcn_rcpf(den);   // den >= 1 (the max term contributes exp(0))
+    }
+}
+
+// d(aggregate)/d(s_v) * g for every view, autograd of the same graph.
+template <int METHOD, int V>
+__device__ __forceinline__ void aggregate_grad(const float (&s)[V], float g, float (&ds)[V])
+{
+    if constexpr (METHOD == AGG_SUM) {
+#pragma unroll
+        for (int v = 0; v < V; ++v) ds[v] = g;
+    } else if constexpr (METHOD == AGG_MEAN) {
+        const float gv = __fdiv_rn(g, (float)V);
+#pragma unroll
+        for (int v = 0; v < V; ++v) ds[v] = gv;
+    } else if constexpr (METHOD == AGG_MAX) {
+        int am = 0;
+#pragma unroll
+        for (int v = 1; v < V; ++v) am = s[v] > s[am] ? v : am;   // first arg-max, as torch.max(dim)
+#pragma unroll
+        for (int v = 0; v < V; ++v) ds[v] = v == am ? g : 0.f;
+    } else {
+        float m = s[0];
+#pragma unroll
+        for (int v = 1; v < V; ++v) m = fmaxf(m, s[v]);
+        const float nm = -m * 1.4426950408889634f;
+        float e[V], den = 0.f, num = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            e[v] = __builtin_amdgcn_exp2f(fmaf(s[v], 1.4426950408889634f, nm));
+            den += e[v];
+            num = fmaf(e[v], s[v], num);
+        }
+        const float rden = __builtin_amdgcn_rcpf(den);
+        const float o = num * rden, gr = g * rden;
+#pragma unroll
+        for (int v = 0; v < V; ++v) ds[v] = gr * e[v] * (1.f + s[v] - o);   // g * p_v * (1 + s_v - out)
+    }
+}
+
+// Running form for a view count only known at run time (V > 8): one pass, same result up to rounding.
+template <int METHOD>
+struct RunningAgg {
+    float m, den, num;
+    __device__ __forceinline__ void init() { m = -INFINITY; den = 0.f; num = 0.f; }
+    __device__ __forceinline__ void push(float s)
+    {
+        if constexpr (METHOD == AGG_SUM || METHOD == AGG_MEAN) num = __fadd_rn(num, s);
+        else if constexpr (METHOD == AGG_MAX) m = fmaxf(m, s);
+        else {
+            const float mn = fmaxf(m, s);
+            const float c = __expf(m - mn), e = __expf(s - mn);   // exp(-inf) = 0 on the first push
+            den = fmaf(den, c, e);
+            num = fmaf(num, c, e * s);
+            m = mn;
+        }
+    }
+    __device__ __forceinline__ float result(int V) const
+    {
+        if constexpr (METHOD == AGG_SUM) return num;
+        else if constexpr (METHOD == AGG_MEAN) return __fdiv_rn(num, (float)V);
+        else if constexpr (METHOD == AGG_MAX) return m;
+        else return num * __builtin_amdgcn_rcpf(den);
+    }
+};
+
+// ---------------------------------------------------------------- typed 4-channel vectors
+struct alignas(16) f32x4 { float v[4]; };
+
+template <typename T> struct Vec4;
+template <> struct Vec4<float> {
+    static __device__ __forceinline__ f32x4 load(const float *p)
+    {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        return f32x4{{t.x, t.y, t.z, t.w}};
+    }
+    static __device__ __forceinline__ void store(float *p, const f32x4 &a)
+    {
+        *reinterpret_cast<float4 *>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    }
+};
+template <> struct Vec4<__half> {
+    static __device__ __forceinline__ f32x4 load(const __half *p)
+    {
+        const uint2 raw = *reinterpret_cast<const uint2 *>(p);
+        const __half2 lo = *reinterpret_cast<const __half2 *>(&raw.x), hi = *reinterpret_cast<const __half2 *>(&raw.y);
+        const float2 a = __half22float2(lo), b = __half22float2(hi);
+        return f32x4{{a.x, a.y, b.x, b.y}};
+    }
+    static __device__ __forceinline__ void store(__half *p, const f32x4 &a)
+    {
+        __half2 lo = __floats2half2_rn(a.v[0], a.v[1]), hi = __floats2half2_rn(a.v[2], a.v[3]);
+        uint2 raw;
+        raw.x = *reinterpret_cast<unsigned *>(&lo);
+        raw.y = *reinterpret_cast<unsigned *>(&hi);
+        *reinterpret_cast<uint2 *>(p) = raw;
+    }
+};
+
+template <typename T> __device__ __forceinline__ float to_f32(T x);
+template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ float to_f32<__half>(__half x) { return __half2float(x); }
+template <typename T> __device__ __forceinline__ T from_f32(float x);
+template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
+template <> __device__ __forceinline__ __half from_f32<__half>(float x) { return __float2half_rn(x); }
+
+__device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ float uniform(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)));
+}
+
+}  // namespace mvhmr

@@ -1,0 +1,40 @@
+// Host-visible launchers of the HIP kernels (internal to the library; the public ABI is include/mvhmr_unproject.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace mvhmr {
+
+struct Problem {
+    int B, V, C, H, W;        // features (B,V,C,H,W)
+    int X, Y, Z;              // volume
+    long long N;              // X*Y*Z
+    int C4;                   // channels rounded up to a multiple of 4 (channels-last row length)
+    int method;               // AGG_*
+    int feat_f16, out_f16;    // storage types
+};
+
+// (B*V, C, HW) -> (B*V, HW, C4), zero-padding channels C..C4; and the inverse for gradients
+// (fp32 channels-last accumulator -> feature dtype, planar).
+hipError_t launch_to_channels_last(const void *src, void *dst, const Problem &p, hipStream_t s);
+hipError_t launch_grad_to_planar(const float *srcT, void *dst, const Problem &p, hipStream_t s);
+// channels-last fp32 accumulator -> channels-last feature dtype (C4 == C required)
+hipError_t launch_grad_cast(const float *srcT, void *dst, const Problem &p, hipStream_t s);
+
+// gather variant: featT is channels-last (B,V,HW,C4) in the feature dtype
+hipError_t launch_fwd_gather(const void *featT, const float *proj, const float *coords, void *out,
+                             const Problem &p, hipStream_t s);
+hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const float *proj, const float *coords,
+                             float *gradT, const Problem &p, hipStream_t s);
+
+// brick variant (LDS-staged patches); returns hipErrorNotSupported when the shape does not qualify
+bool brick_supported(const Problem &p);
+size_t brick_workspace_bytes(const Problem &p);
+hipError_t launch_fwd_brick(const void *features, bool channels_last_in, const float *proj, const float *coords,
+                            void *out, void *workspace, const Problem &p, hipStream_t s);
+
+hipError_t launch_build_coords(float *coords, const float *rot, const float *center, int B, int S,
+                               const double pos[3], const double sides[3], hipStream_t s);
+
+}  // namespace mvhmr

@@ -1,0 +1,447 @@
+// "gather" variant of the fused un-projection: the shape-agnostic kernel pair.
+//
+// Mapping (CDNA4, wave64):
+//   block   = 64 consecutive voxels x one group of up to 256 channels of one sample (256 threads, 4 waves)
+//   phase 1 = one thread per (voxel, view): project, build the 4 bilinear taps -> 32-byte record in LDS
+//             (done once, reused by every channel: models/aggregation.py:38-54 hoisted out of the channel dim)
+//   phase 2 = one wave per voxel, one LANE per 4 consecutive channels: the tap records are wave-uniform
+//             (SGPRs), each tap is ONE coalesced 1-KiB read of a channels-last feature row, the
+//             cross-view aggregate runs in registers (no (V,C,N) intermediate, aggregation.py:32,68,78-83)
+//   phase 3 = the (voxel x channel) tile is turned through LDS so every store is a full 256-B row of
+//             consecutive voxels of one channel of the (B,C,X,Y,Z) output
+// Feature reads come from L2 / Infinity Cache (each (b,v) map is re-read by many blocks), the output is
+// written exactly once.  The brick variant (unproject_brick.hip) replaces the L2 gather by LDS patches.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace mvhmr {
+
+constexpr int kTileVox = 64;
+constexpr int kGroupQuads = 64;      // 64 lanes x 4 channels
+constexpr int kGroupCh = 256;
+
+struct alignas(16) TapRec {
+    int o00, o01, o10, o11;          // element offsets (pixel * C4) inside one (b,v) channels-last map
+    float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ void build_records(TapRec *recs, const float *__restrict__ proj,
+                                              const float *__restrict__ coords, int b, int V, long long n0,
+                                              long long N, int H, int W, int C4)
+{
+    for (int idx = threadIdx.x; idx < kTileVox * V; idx += blockDim.x) {
+        const int v = idx >> 6, j = idx & 63;
+        long long n = n0 + j;
+        n = n < N ? n : N - 1;       // tail voxels are computed and dropped
+        const float *X = coords + ((long long)b * N + n) * 3;
+        const Taps t = make_taps(proj + ((long long)b * V + v) * 12, X[0], X[1], X[2], H, W);
+        TapRec r;
+        r.o00 = (t.y0 * W + t.x0) * C4;
+        r.o01 = (t.y0 * W + t.x1) * C4;
+        r.o10 = (t.y1 * W + t.x0) * C4;
+        r.o11 = (t.y1 * W + t.x1) * C4;
+        r.w00 = t.w00; r.w01 = t.w01; r.w10 = t.w10; r.w11 = t.w11;
+        recs[j * V + v] = r;
+    }
+}
+
+struct UTap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
+__device__ __forceinline__ UTap uniform_rec(const TapRec &r)
+{
+    UTap u;
+    u.o00 = uniform(r.o00); u.o01 = uniform(r.o01); u.o10 = uniform(r.o10); u.o11 = uniform(r.o11);
+    u.w00 = uniform(r.w00); u.w01 = uniform(r.w01); u.w10 = uniform(r.w10); u.w11 = uniform(r.w11);
+    return u;
+}
+
+// ------------------------------------------------------------------------------------------ forward
+template <typename TF, typename TO, int METHOD, int VT>
+__global__ void __launch_bounds__(256)
+k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const float *__restrict__ coords,
+             TO *__restrict__ out, int Vrt, int C, int C4, int H, int W, long long N, int tstride)
+{
+    const int V = VT > 0 ? VT : Vrt;
+    extern __shared__ __align__(16) unsigned char smem[];
+    TapRec *recs = reinterpret_cast<TapRec *>(smem);
+    f32x4 *tile = reinterpret_cast<f32x4 *>(smem + sizeof(TapRec) * kTileVox * V);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, cg = blockIdx.z;
+    const long long n0 = (long long)blockIdx.x * kTileVox;
+    const long long mapsz = (long long)H * W * C4;
+    const int Q = C4 >> 2;
+
+    build_records(recs, proj, coords, b, V, n0, N, H, W, C4);
+    __syncthreads();
+
+    int q = cg * kGroupQuads + lane;
+    q = q < Q ? q : Q - 1;                                   // idle lanes shadow the last quad, never stored
+    const TF *fb = featT + (long long)b * V * mapsz + q * 4;
+
+    for (int jj = 0; jj < kTileVox / 4; ++jj) {
+        const int j = wave * (kTileVox / 4) + jj;
+        f32x4 o;
+        if constexpr (VT > 0) {
+            float s[4][VT];
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                const UTap u = uniform_rec(recs[j * VT + v]);
+                const TF *fv = fb + v * mapsz;
+                const f32x4 a = Vec4<TF>::load(fv + u.o00), bb = Vec4<TF>::load(fv + u.o01);
+                const f32x4 c = Vec4<TF>::load(fv + u.o10), d = Vec4<TF>::load(fv + u.o11);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i][v] = bilerp(a.v[i], bb.v[i], c.v[i], d.v[i], u.w00, u.w01, u.w10, u.w11);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o.v[i] = aggregate<METHOD, VT>(s[i]);
+        } else {
+            RunningAgg<METHOD> ra[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i].init();
+            for (int v = 0; v < V; ++v) {
+                const UTap u = uniform_rec(recs[j * V + v]);
+                const TF *fv = fb + v * mapsz;
+                const f32x4 a = Vec4<TF>::load(fv + u.o00), bb = Vec4<TF>::load(fv + u.o01);
+                const f32x4 c = Vec4<TF>::load(fv + u.o10), d = Vec4<TF>::load(fv + u.o11);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ra[i].push(bilerp(a.v[i], bb.v[i], c.v[i], d.v[i], u.w00, u.w01, u.w10, u.w11));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o.v[i] = ra[i].result(V);
+        }
+        tile[j * tstride + lane] = o;
+    }
+    __syncthreads();
+
+    // lane = voxel now: each store instruction writes 64 consecutive voxels of one channel
+    const long long n = n0 + lane;
+    if (n < N) {
+        for (int qq = wave * 16; qq < wave * 16 + 16; ++qq) {
+            const int cq = cg * kGroupQuads + qq;
+            if (cq >= Q) break;
+            const f32x4 t = tile[lane * tstride + qq];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = cq * 4 + i;
+                if (c < C) out[((long long)b * C + c) * N + n] = from_f32<TO>(t.v[i]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ backward
+// lane <-> channels {l, l+64, l+128, l+192} of the group so that every float-atomic wave instruction
+// adds 256 contiguous bytes of the channels-last gradient row (the full-rate shape on gfx950).
+template <typename TF, typename TO, int METHOD, int VT>
+__global__ void __launch_bounds__(256)
+k_bwd_gather(const TO *__restrict__ grad_out, const TF *__restrict__ featT, const float *__restrict__ proj,
+             const float *__restrict__ coords, float *__restrict__ gradT, int Vrt, int C, int C4, int H, int W,
+             long long N)
+{
+    const int V = VT > 0 ? VT : Vrt;
+    extern __shared__ __align__(16) unsigned char smem[];
+    TapRec *recs = reinterpret_cast<TapRec *>(smem);
+    float *gtile = reinterpret_cast<float *>(smem + sizeof(TapRec) * kTileVox * V);   // [256 ch][65]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, cg = blockIdx.z;
+    const long long n0 = (long long)blockIdx.x * kTileVox;
+    const long long mapsz = (long long)H * W * C4;
+
+    build_records(recs, proj, coords, b, V, n0, N, H, W, C4);
+    {   // grad_out tile, coalesced along voxels
+        const long long n = n0 + lane;
+        for (int r = wave * 64; r < wave * 64 + 64; ++r) {
+            const int c = cg * kGroupCh + r;
+            float g = 0.f;
+            if (c < C && n < N) g = to_f32<TO>(grad_out[((long long)b * C + c) * N + n]);
+            gtile[r * 65 + lane] = g;
+        }
+    }
+    __syncthreads();
+
+    int ch[4];
+    bool act[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = cg * kGroupCh + i * 64 + lane;
+        act[i] = c < C;
+        ch[i] = act[i] ? c : 0;
+    }
+    const TF *fb = featT + (long long)b * V * mapsz;
+    float *gb = gradT + (long long)b * V * mapsz;
+
+    auto sample4 = [&](const UTap &u, int v, float (&sv)[4]) {
+        const TF *fv = fb + v * mapsz;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            sv[i] = bilerp(to_f32<TF>(fv[u.o00 + ch[i]]), to_f32<TF>(fv[u.o01 + ch[i]]), to_f32<TF>(fv[u.o10 + ch[i]]),
+                           to_f32<TF>(fv[u.o11 + ch[i]]), u.w00, u.w01, u.w10, u.w11);
+    };
+    auto scatter4 = [&](const UTap &u, int v, const float (&dsv)[4]) {
+        float *gv = gb + v * mapsz;
+        // zero-weight taps (outside the map, or z <= 0) receive nothing -- wave-uniform branches
+        if (u.w00 != 0.f) { for (int i = 0; i < 4; ++i) if (act[i]) atomicAdd(gv + u.o00 + ch[i], dsv[i] * u.w00); }
+        if (u.w01 != 0.f) { for (int i = 0; i < 4; ++i) if (act[i]) atomicAdd(gv + u.o01 + ch[i], dsv[i] * u.w01); }
+        if (u.w10 != 0.f) { for (int i = 0; i < 4; ++i) if (act[i]) atomicAdd(gv + u.o10 + ch[i], dsv[i] * u.w10); }
+        if (u.w11 != 0.f) { for (int i = 0; i < 4; ++i) if (act[i]) atomicAdd(gv + u.o11 + ch[i], dsv[i] * u.w11); }
+    };
+
+    for (int jj = 0; jj < kTileVox / 4; ++jj) {
+        const int j = wave * (kTileVox / 4) + jj;
+        if (n0 + j >= N) break;
+        float g[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) g[i] = gtile[(i * 64 + lane) * 65 + j];
+
+        if constexpr (VT > 0) {
+            float s[4][VT], ds[4][VT];
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                float sv[4];
+                sample4(uniform_rec(recs[j * VT + v]), v, sv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i][v] = sv[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) aggregate_grad<METHOD, VT>(s[i], g[i], ds[i]);
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                const float dsv[4] = {ds[0][v], ds[1][v], ds[2][v], ds[3][v]};
+                scatter4(uniform_rec(recs[j * VT + v]), v, dsv);
+            }
+        } else {
+            // run-time view count: pass 1 accumulates the aggregate, pass 2 re-samples and scatters
+            RunningAgg<METHOD> ra[4];
+            int am[4] = {0, 0, 0, 0};
+            float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i].init();
+            for (int v = 0; v < V; ++v) {
+                float sv[4];
+                sample4(uniform_rec(recs[j * V + v]), v, sv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ra[i].push(sv[i]);
+                    if (sv[i] > best[i]) { best[i] = sv[i]; am[i] = v; }
+                }
+            }
+            for (int v = 0; v < V; ++v) {
+                const UTap u = uniform_rec(recs[j * V + v]);
+                float sv[4], dsv[4];
+                sample4(u, v, sv);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (METHOD == AGG_SUM) dsv[i] = g[i];
+                    else if constexpr (METHOD == AGG_MEAN) dsv[i] = __fdiv_rn(g[i], (float)V);
+                    else if constexpr (METHOD == AGG_MAX) dsv[i] = am[i] == v ? g[i] : 0.f;
+                    else {
+                        const float rden = __builtin_amdgcn_rcpf(ra[i].den);
+                        const float o = ra[i].num * rden;
+                        dsv[i] = g[i] * __expf(sv[i] - ra[i].m) * rden * (1.f + sv[i] - o);
+                    }
+                }
+                scatter4(u, v, dsv);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ layout passes
+// (BV, C, HW) -> (BV, HW, C4): 64 x 64 tiles turned through LDS, both sides coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_to_channels_last(const T *__restrict__ src, T *__restrict__ dst, int C, int C4, int HW)
+{
+    __shared__ T t[64][65];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long bv = blockIdx.z;
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    for (int r = w; r < 64; r += 4) {
+        const int c = c0 + r, p = p0 + lane;
+        t[r][lane] = (c < C && p < HW) ? src[(bv * C + c) * HW + p] : from_f32<T>(0.f);
+    }
+    __syncthreads();
+    for (int r = w; r < 64; r += 4) {
+        const int p = p0 + r, c = c0 + lane;
+        if (p < HW && c < C4) dst[(bv * HW + p) * C4 + c] = t[lane][r];
+    }
+}
+
+// fp32 channels-last gradient accumulator (BV, HW, C4) -> (BV, C, HW) in the feature dtype
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_grad_to_planar(const float *__restrict__ srcT, T *__restrict__ dst, int C, int C4, int HW)
+{
+    __shared__ float t[64][65];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long bv = blockIdx.z;
+    const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    for (int r = w; r < 64; r += 4) {
+        const int p = p0 + r, c = c0 + lane;
+        t[r][lane] = (p < HW && c < C4) ? srcT[(bv * HW + p) * C4 + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = w; r < 64; r += 4) {
+        const int c = c0 + r, p = p0 + lane;
+        if (c < C && p < HW) dst[(bv * C + c) * HW + p] = from_f32<T>(t[lane][r]);
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) k_grad_cast(const float *__restrict__ src, T *__restrict__ dst, long long n)
+{
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        dst[i] = from_f32<T>(src[i]);
+}
+
+// coords[b,i,j,k,:] = rot[b] @ (pos + step * (i,j,k) - center[b]) + center[b]   (aggregation.py:150-187)
+__global__ void __launch_bounds__(256)
+k_build_coords(float *__restrict__ coords, const float *__restrict__ rot, const float *__restrict__ center, int S,
+               float px, float py, float pz, float sx, float sy, float sz)
+{
+    const int b = blockIdx.y;
+    const long long N = (long long)S * S * S;
+    const long long n = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int k = (int)(n % S), j = (int)((n / S) % S), i = (int)(n / ((long long)S * S));
+    const float *R = rot + b * 9, *ce = center + b * 3;
+    // grid_coord = position + (sides / (S-1)) * grid   (fp32 mul then add, aggregation.py:157-159)
+    const float gx = __fadd_rn(px, __fmul_rn(sx, (float)i));
+    const float gy = __fadd_rn(py, __fmul_rn(sy, (float)j));
+    const float gz = __fadd_rn(pz, __fmul_rn(sz, (float)k));
+    const float dx = __fsub_rn(gx, ce[0]), dy = __fsub_rn(gy, ce[1]), dz = __fsub_rn(gz, ce[2]);   // :184
+    float *o = coords + ((long long)b * N + n) * 3;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {                                                                      // :185, volumetric.py:110
+        const float acc = __fmaf_rn(R[r * 3 + 2], dz, __fmaf_rn(R[r * 3 + 1], dy, __fmul_rn(R[r * 3 + 0], dx)));
+        o[r] = __fadd_rn(acc, ce[r]);                                                                  // :186
+    }
+}
+
+// ------------------------------------------------------------------------------------------ launchers
+template <typename TF, typename TO, int METHOD>
+static hipError_t fwd_dispatch_v(const TF *featT, const float *proj, const float *coords, TO *out, const Problem &p,
+                                 hipStream_t s)
+{
+    const int Q = p.C4 / 4;
+    int tstride = (Q < kGroupQuads ? Q : kGroupQuads) + 1;
+    tstride |= 1;
+    const size_t lds = sizeof(TapRec) * kTileVox * (size_t)p.V + sizeof(f32x4) * kTileVox * (size_t)tstride;
+    const dim3 grid((unsigned)((p.N + kTileVox - 1) / kTileVox), (unsigned)p.B, (unsigned)((Q + kGroupQuads - 1) / kGroupQuads));
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, featT, proj, coords, out, p.V, p.C, p.C4, p.H, p.W, p.N, tstride);
+        return hipGetLastError();
+    };
+    switch (p.V) {
+    case 2: return go(k_fwd_gather<TF, TO, METHOD, 2>);
+    case 4: return go(k_fwd_gather<TF, TO, METHOD, 4>);
+    case 8: return go(k_fwd_gather<TF, TO, METHOD, 8>);
+    default: return go(k_fwd_gather<TF, TO, METHOD, 0>);
+    }
+}
+
+template <typename TF, typename TO>
+static hipError_t fwd_dispatch_m(const TF *featT, const float *proj, const float *coords, TO *out, const Problem &p,
+                                 hipStream_t s)
+{
+    switch (p.method) {
+    case AGG_SOFTMAX: return fwd_dispatch_v<TF, TO, AGG_SOFTMAX>(featT, proj, coords, out, p, s);
+    case AGG_SUM: return fwd_dispatch_v<TF, TO, AGG_SUM>(featT, proj, coords, out, p, s);
+    case AGG_MEAN: return fwd_dispatch_v<TF, TO, AGG_MEAN>(featT, proj, coords, out, p, s);
+    case AGG_MAX: return fwd_dispatch_v<TF, TO, AGG_MAX>(featT, proj, coords, out, p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_fwd_gather(const void *featT, const float *proj, const float *coords, void *out, const Problem &p,
+                             hipStream_t s)
+{
+    if (!p.feat_f16 && !p.out_f16) return fwd_dispatch_m((const float *)featT, proj, coords, (float *)out, p, s);
+    if (p.feat_f16 && p.out_f16) return fwd_dispatch_m((const __half *)featT, proj, coords, (__half *)out, p, s);
+    if (p.feat_f16 && !p.out_f16) return fwd_dispatch_m((const __half *)featT, proj, coords, (float *)out, p, s);
+    return hipErrorNotSupported;
+}
+
+template <typename TF, typename TO, int METHOD>
+static hipError_t bwd_dispatch_v(const TO *go_, const TF *featT, const float *proj, const float *coords, float *gradT,
+                                 const Problem &p, hipStream_t s)
+{
+    const size_t lds = sizeof(TapRec) * kTileVox * (size_t)p.V + sizeof(float) * kGroupCh * 65;
+    const dim3 grid((unsigned)((p.N + kTileVox - 1) / kTileVox), (unsigned)p.B, (unsigned)((p.C + kGroupCh - 1) / kGroupCh));
+    auto go = [&](auto kern) -> hipError_t {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, go_, featT, proj, coords, gradT, p.V, p.C, p.C4, p.H, p.W, p.N);
+        return hipGetLastError();
+    };
+    switch (p.V) {
+    case 2: return go(k_bwd_gather<TF, TO, METHOD, 2>);
+    case 4: return go(k_bwd_gather<TF, TO, METHOD, 4>);
+    case 8: return go(k_bwd_gather<TF, TO, METHOD, 8>);
+    default: return go(k_bwd_gather<TF, TO, METHOD, 0>);
+    }
+}
+
+template <typename TF, typename TO>
+static hipError_t bwd_dispatch_m(const TO *go_, const TF *featT, const float *proj, const float *coords, float *gradT,
+                                 const Problem &p, hipStream_t s)
+{
+    switch (p.method) {
+    case AGG_SOFTMAX: return bwd_dispatch_v<TF, TO, AGG_SOFTMAX>(go_, featT, proj, coords, gradT, p, s);
+    case AGG_SUM: return bwd_dispatch_v<TF, TO, AGG_SUM>(go_, featT, proj, coords, gradT, p, s);
+    case AGG_MEAN: return bwd_dispatch_v<TF, TO, AGG_MEAN>(go_, featT, proj, coords, gradT, p, s);
+    case AGG_MAX: return bwd_dispatch_v<TF, TO, AGG_MAX>(go_, featT, proj, coords, gradT, p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const float *proj, const float *coords,
+                             float *gradT, const Problem &p, hipStream_t s)
+{
+    if (!p.feat_f16 && !p.out_f16) return bwd_dispatch_m((const float *)grad_out, (const float *)featT, proj, coords, gradT, p, s);
+    if (p.feat_f16 && p.out_f16) return bwd_dispatch_m((const __half *)grad_out, (const __half *)featT, proj, coords, gradT, p, s);
+    if (p.feat_f16 && !p.out_f16) return bwd_dispatch_m((const float *)grad_out, (const __half *)featT, proj, coords, gradT, p, s);
+    return hipErrorNotSupported;
+}
+
+hipError_t launch_to_channels_last(const void *src, void *dst, const Problem &p, hipStream_t s)
+{
+    const int HW = p.H * p.W;
+    const dim3 grid((HW + 63) / 64, (p.C4 + 63) / 64, (unsigned)(p.B * p.V));
+    if (p.feat_f16) hipLaunchKernelGGL(k_to_channels_last<__half>, grid, dim3(256), 0, s, (const __half *)src, (__half *)dst, p.C, p.C4, HW);
+    else hipLaunchKernelGGL(k_to_channels_last<float>, grid, dim3(256), 0, s, (const float *)src, (float *)dst, p.C, p.C4, HW);
+    return hipGetLastError();
+}
+
+hipError_t launch_grad_to_planar(const float *srcT, void *dst, const Problem &p, hipStream_t s)
+{
+    const int HW = p.H * p.W;
+    const dim3 grid((HW + 63) / 64, (p.C4 + 63) / 64, (unsigned)(p.B * p.V));
+    if (p.feat_f16) hipLaunchKernelGGL(k_grad_to_planar<__half>, grid, dim3(256), 0, s, srcT, (__half *)dst, p.C, p.C4, HW);
+    else hipLaunchKernelGGL(k_grad_to_planar<float>, grid, dim3(256), 0, s, srcT, (float *)dst, p.C, p.C4, HW);
+    return hipGetLastError();
+}
+
+hipError_t launch_grad_cast(const float *srcT, void *dst, const Problem &p, hipStream_t s)
+{
+    const long long n = (long long)p.B * p.V * p.H * p.W * p.C4;
+    const unsigned blocks = (unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    if (p.feat_f16) hipLaunchKernelGGL(k_grad_cast<__half>, dim3(blocks), dim3(256), 0, s, srcT, (__half *)dst, n);
+    else hipLaunchKernelGGL(k_grad_cast<float>, dim3(blocks), dim3(256), 0, s, srcT, (float *)dst, n);
+    return hipGetLastError();
+}
+
+hipError_t launch_build_coords(float *coords, const float *rot, const float *center, int B, int S, const double pos[3],
+                               const double sides[3], hipStream_t s)
+{
+    const long long N = (long long)S * S * S;
+    const double d = (double)(S - 1);
+    // step = sides / (S-1) and position are float64 scalars in the reference, cast to fp32 when they meet the tensor
+    const float sx = (float)(sides[0] / d), sy = (float)(sides[1] / d), sz = (float)(sides[2] / d);
+    hipLaunchKernelGGL(k_build_coords, dim3((unsigned)((N + 255) / 256), (unsigned)B), dim3(256), 0, s, coords, rot, center, S,
+                       (float)pos[0], (float)pos[1], (float)pos[2], sx, sy, sz);
+    return hipGetLastError();
+}
+
+}  // namespace mvhmr

@@ -1,0 +1,276 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the reference's golden vectors and the
+CPU oracle on the same seeded inputs.  Tolerance for fp32: 1e-4 max-abs (BASELINE.json north_star);
+the kernels mirror the reference's rounding order, so the observed error is ~1e-6 and the asserts below
+use the north-star bar scaled only by the output magnitude where values are far above O(1)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_cases, load_golden
+from multiviewhmr_amd import _capi, aggregation, multiview
+from oracle import cport
+
+pytestmark = pytest.mark.gpu
+MODES = ("softmax", "sum", "mean", "max")
+TOL = 1e-4                      # fp32 bar from BASELINE.json
+VARIANTS = ("gather", "auto")
+
+
+def _dev(d, key, gpu, dtype=torch.float32):
+    return torch.from_numpy(d[key]).to(device=gpu, dtype=dtype)
+
+
+def _scale(ref):
+    return max(1.0, float(np.abs(ref).max()) / 8.0)     # goldens are O(1..8) except the saturated case
+
+
+# ------------------------------------------------------------------------------------ goldens, forward + backward
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("case", golden_cases("unproj"))
+def test_forward_matches_reference_goldens(case, variant, gpu):
+    d = load_golden("unproj", case)
+    f, p, c = _dev(d, "features", gpu), _dev(d, "proj", gpu), _dev(d, "coords", gpu)
+    for mode in MODES:
+        if "out_" + mode not in d:
+            continue
+        out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant=variant)
+        ref = d["out_" + mode]
+        assert out.dtype == torch.float32 and tuple(out.shape) == ref.shape and out.device == f.device
+        err = float(np.abs(out.cpu().numpy() - ref).max())
+        assert err <= TOL * _scale(ref), (case, mode, err)
+
+
+@pytest.mark.parametrize("case", golden_cases("unproj"))
+def test_backward_matches_reference_goldens(case, gpu):
+    d = load_golden("unproj", case)
+    p, c, go = _dev(d, "proj", gpu), _dev(d, "coords", gpu), _dev(d, "grad_out", gpu)
+    for mode in MODES:
+        if "gfeat_" + mode not in d:
+            continue
+        f = _dev(d, "features", gpu).requires_grad_(True)
+        out = aggregation.unprojection(f, p, c, aggregation_method=mode)
+        out.backward(go)
+        ref = d["gfeat_" + mode]
+        err = float(np.abs(f.grad.cpu().numpy() - ref).max())
+        assert err <= TOL * _scale(ref), (case, mode, err)     # float atomics: order-dependent low bits only
+
+
+def test_inputs_are_not_mutated_and_output_is_fresh(gpu):
+    d = load_golden("unproj", "adversarial_v4c6")
+    f, p, c = _dev(d, "features", gpu), _dev(d, "proj", gpu), _dev(d, "coords", gpu)
+    f0, p0, c0 = f.clone(), p.clone(), c.clone()
+    a = aggregation.unprojection(f, p, c)
+    b = aggregation.unprojection(f, p, c)
+    assert a.data_ptr() != b.data_ptr() and torch.equal(a, b)             # forward is deterministic
+    assert torch.equal(f, f0) and torch.equal(p, p0) and torch.equal(c, c0)
+
+
+# ------------------------------------------------------------------------------------ seeded inputs vs the oracle
+def _ring_problem(B, V, C, H, W, vol, seed, theta=0.3):
+    rng = np.random.default_rng(seed)
+    feats = rng.standard_normal((B, V, C, H, W), dtype=np.float32)
+    proj = np.empty((B, V, 3, 4), np.float32)
+    for b in range(B):
+        for v in range(V):
+            az = 2 * np.pi * v / V + 0.3 + 0.1 * b
+            eye = np.array([5000 * np.cos(az), 5000 * np.sin(az), 1500.0])
+            fwd = -eye / np.linalg.norm(eye)
+            right = np.cross(fwd, [0, 0, 1.0]); right /= np.linalg.norm(right)
+            R = np.stack([right, np.cross(fwd, right), fwd])
+            cam = multiview.Camera(R, -R @ eye, [[1145.0, 0, 512], [0, 1145.0, 512], [0, 0, 1]])
+            cam.update_after_crop((150, 150, 850, 850))
+            cam.update_after_resize((700, 700), (4 * W, 4 * H))
+            cam.update_after_resize((4 * H, 4 * W), (H, W))
+            proj[b, v] = cam.projection
+    X, Y, Z = vol
+    g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij"), -1).astype(np.float64)
+    pts = -1250.0 + g * (2500.0 / (np.array([X, Y, Z]) - 1))
+    ct, st = np.cos(theta), np.sin(theta)
+    pts = pts @ np.array([[ct, -st, 0], [st, ct, 0], [0, 0, 1.0]]).T
+    coords = np.broadcast_to(pts.astype(np.float32), (B,) + pts.shape).copy()
+    return feats, proj, coords
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=2, V=4, C=64, H=48, W=48, vol=(16, 16, 32)),       # V=4 compiled path, several channel quads
+    dict(B=1, V=3, C=20, H=24, W=40, vol=(9, 7, 13)),         # run-time V path, N % 64 != 0, non-square map
+    dict(B=1, V=5, C=6, H=16, W=16, vol=(5, 5, 5)),           # C % 4 != 0, run-time V
+    dict(B=1, V=8, C=300, H=24, W=24, vol=(4, 8, 16)),        # two channel groups (C > 256), V=8 compiled path
+    dict(B=3, V=2, C=16, H=32, W=32, vol=(8, 8, 8)),          # V=2 compiled path
+    dict(B=1, V=12, C=8, H=16, W=16, vol=(4, 4, 8)),          # many views (run-time path, > 8)
+])
+@pytest.mark.parametrize("mode", MODES)
+def test_forward_and_backward_vs_oracle(shape, mode, gpu):
+    feats, proj, coords = _ring_problem(seed=MODES.index(mode) * 100 + shape["C"], **shape)
+    f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    out = aggregation.unprojection(f, p, c, aggregation_method=mode)
+    ref = cport.forward(feats, proj, coords, mode)
+    assert float(np.abs(out.detach().cpu().numpy() - ref).max()) <= TOL
+    go = np.random.default_rng(5).standard_normal(ref.shape, dtype=np.float32)
+    out.backward(torch.from_numpy(go).to(gpu))
+    gref = cport.backward(go, feats, proj, coords, mode)
+    assert float(np.abs(f.grad.cpu().numpy() - gref).max()) <= TOL * max(1.0, float(np.abs(gref).max()) / 8.0)
+
+
+def test_channels_last_features_skip_the_layout_pass(gpu):
+    feats, proj, coords = _ring_problem(B=2, V=4, C=32, H=24, W=24, vol=(8, 8, 16), seed=3)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    planar = torch.from_numpy(feats).to(gpu)
+    cl = planar.permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)       # (B,V,C,H,W) view of (B,V,H,W,C) memory
+    assert not cl.is_contiguous() and aggregation._is_channels_last5(cl)
+    a = aggregation.unprojection(planar, p, c)
+    cl = cl.detach().requires_grad_(True)
+    b = aggregation.unprojection(cl, p, c)
+    assert torch.equal(a, b)
+    go = torch.randn_like(b)
+    b.backward(go)
+    pl = planar.detach().requires_grad_(True)
+    aggregation.unprojection(pl, p, c).backward(go)
+    assert cl.grad.shape == cl.shape
+    assert float((cl.grad - pl.grad).abs().max()) <= 1e-5
+
+
+def test_fp16_storage_mode(gpu):
+    """fp16 features / volume, fp32 geometry and accumulation; oracle evaluated on the fp16-rounded inputs.
+    Bound: half an fp16 ulp of the output magnitude (~2^-11 * |x|) plus the fp32 bar."""
+    feats, proj, coords = _ring_problem(B=1, V=4, C=32, H=32, W=32, vol=(8, 8, 32), seed=11)
+    f16 = torch.from_numpy(feats).to(gpu).half()
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    ref = cport.forward(f16.float().cpu().numpy(), proj, coords, "softmax")
+    out16 = aggregation.unprojection(f16, p, c)
+    assert out16.dtype == torch.float16
+    bound = TOL + np.abs(ref).max() * 2.0 ** -11
+    assert float(np.abs(out16.float().cpu().numpy() - ref).max()) <= bound
+    out32 = aggregation.unprojection(f16, p, c, out_dtype=torch.float32)
+    assert out32.dtype == torch.float32 and float(np.abs(out32.cpu().numpy() - ref).max()) <= TOL
+    f16g = f16.clone().requires_grad_(True)
+    go = torch.randn_like(out16)
+    aggregation.unprojection(f16g, p, c).backward(go)
+    gref = cport.backward(go.float().cpu().numpy(), f16.float().cpu().numpy(), proj, coords, "softmax")
+    gb = TOL + np.abs(gref).max() * 2.0 ** -10
+    assert f16g.grad.dtype == torch.float16 and float(np.abs(f16g.grad.float().cpu().numpy() - gref).max()) <= gb
+
+
+# ------------------------------------------------------------------------------------ size-independent properties at BASELINE config[1]
+@pytest.fixture(scope="module")
+def config1(gpu):
+    """32^3 grid, 4 views, 256 ch, 96x96 maps, batch 8 fp32 (BASELINE.json configs[1])."""
+    feats, proj, coords = _ring_problem(B=8, V=4, C=256, H=96, W=96, vol=(32, 32, 32), seed=1, theta=0.0)
+    return torch.from_numpy(feats).to(gpu), torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+
+
+def test_config1_properties(config1):
+    f, p, c = config1
+    V = f.shape[1]
+    s = aggregation.unprojection(f, p, c, aggregation_method="sum")
+    # mean == sum / V, max >= mean, softmax-weighted mean lies between mean and max
+    mean = aggregation.unprojection(f, p, c, aggregation_method="mean")
+    mx = aggregation.unprojection(f, p, c, aggregation_method="max")
+    sm = aggregation.unprojection(f, p, c, aggregation_method="softmax")
+    assert float((mean - s / V).abs().max()) <= 1e-6
+    assert bool((mx >= mean - 1e-6).all()) and bool((sm <= mx + 1e-5).all()) and bool((sm >= mean - 1e-5).all())
+    # 'sum' is linear in the features
+    g = torch.randn_like(f)
+    s2 = aggregation.unprojection(2.0 * f + g, p, c, aggregation_method="sum")
+    sg = aggregation.unprojection(g, p, c, aggregation_method="sum")
+    assert float((s2 - (2.0 * s + sg)).abs().max()) <= 2e-5
+    # the aggregate does not care about the order of the views
+    perm = torch.tensor([2, 0, 3, 1], device=f.device)
+    smp = aggregation.unprojection(f[:, perm].contiguous(), p[:, perm].contiguous(), c, aggregation_method="softmax")
+    assert float((smp - sm).abs().max()) <= 2e-6
+    # samples are independent: a batch shard equals the same rows of the full batch (what multi-GPU sharding relies on)
+    half = aggregation.unprojection(f[4:].contiguous(), p[4:].contiguous(), c[4:].contiguous())
+    assert torch.equal(half, sm[4:])
+    # constant feature maps: every in-frustum voxel aggregates to that constant (weights sum to 1)
+    ones = torch.full_like(f, 1.5)
+    so = aggregation.unprojection(ones, p, c, aggregation_method="max")
+    assert float(so.max()) <= 1.5 + 1e-5 and float(so.min()) >= 0.0
+    assert float(((so - 1.5).abs() <= 1e-5).float().mean()) > 0.3
+
+
+def test_config1_sample_vs_oracle(config1):
+    """Full BASELINE config[1] inputs, checked against the oracle on one sample (keeps the CPU side to seconds)."""
+    f, p, c = config1
+    out = aggregation.unprojection(f, p, c)
+    ref = cport.forward(f[5:6].cpu().numpy(), p[5:6].cpu().numpy(), c[5:6].cpu().numpy(), "softmax")
+    assert float(np.abs(out[5:6].cpu().numpy() - ref).max()) <= TOL
+
+
+# ------------------------------------------------------------------------------------ VolumeGenerator end to end
+def _rebuild(d, gpu):
+    B, V, C_in, C_out, S, training, use_tri, seed = (int(x) for x in d["meta"])
+    cams = [[multiview.Camera(d["R"][v, b], d["t"][v, b], d["K"][v, b]) for b in range(B)] for v in range(V)]
+    batch = dict(images=np.zeros((B, V, int(d["image_hw"][0]), int(d["image_hw"][1]), 3), dtype=np.uint8),
+                 cameras=cams, keypoints_3d=[k for k in d["keypoints"]])
+    gen = aggregation.VolumeGenerator(volume_size=S, input_channels=C_in, output_channels=C_out, cuboid_side=2500.0,
+                                      use_triangulation=bool(use_tri), kind=str(d["kind"]), device=gpu)
+    gen.load_state_dict({"process_feature.0.weight": torch.from_numpy(d["weight"]),
+                         "process_feature.0.bias": torch.from_numpy(d["bias"])})
+    gen.train(bool(training))
+    return gen, batch, seed
+
+
+@pytest.mark.parametrize("case", golden_cases("volgen"))
+def test_volume_generator_end_to_end(case, gpu):
+    d = load_golden("volgen", case)
+    gen, batch, seed = _rebuild(d, gpu)
+    np.random.seed(seed)
+    rots, centers = gen.volume_pose(batch, _dev(d, "proj_org", gpu), tuple(batch["images"].shape[2:-1]))
+    coords = gen.coord_volumes(rots, centers, gpu)
+    tri = bool(int(d["meta"][6]))
+    assert float(np.abs(coords.cpu().numpy() - d["coords"]).max()) <= (5e-2 if tri else 1e-3)
+    np.random.seed(seed)
+    with torch.no_grad():
+        vol = gen(_dev(d, "features_in", gpu), _dev(d, "proj_org", gpu), batch)
+    assert vol.dtype == torch.float32 and tuple(vol.shape) == d["volume"].shape
+    # the triangulated pivot goes through an SVD on another backend; everything else sits on the fp32 bar
+    assert float(np.abs(vol.cpu().numpy() - d["volume"]).max()) <= (2e-3 if tri else TOL)
+
+
+def test_volume_generator_trains(gpu):
+    d = load_golden("volgen", "train_mpii")
+    gen, batch, seed = _rebuild(d, gpu)
+    np.random.seed(seed)
+    feats = _dev(d, "features_in", gpu).requires_grad_(True)
+    vol = gen(feats, _dev(d, "proj_org", gpu), batch)
+    vol.square().mean().backward()
+    w = gen.process_feature[0].weight
+    assert w.grad is not None and torch.isfinite(w.grad).all() and float(w.grad.abs().sum()) > 0
+    assert feats.grad is not None and torch.isfinite(feats.grad).all()
+
+
+# ------------------------------------------------------------------------------------ raw C ABI
+def test_raw_c_abi_call(gpu):
+    """Bind the library the way INTEGRATION.md shows (plain pointers + sizes), no package helpers."""
+    d = load_golden("unproj", "tiles_v4c16")
+    f, p, c = _dev(d, "features", gpu), _dev(d, "proj", gpu), _dev(d, "coords", gpu)
+    L = ctypes.CDLL(_capi.LIB_PATH)
+    L.mvhmr_unproject_forward_workspace_bytes.restype = ctypes.c_size_t
+    desc = _capi.Desc()
+    desc.abi_version = 1
+    desc.batch, desc.views, desc.channels, desc.feat_h, desc.feat_w = f.shape
+    desc.vol_x, desc.vol_y, desc.vol_z = c.shape[1:4]
+    desc.method, desc.feat_dtype, desc.out_dtype, desc.feat_layout, desc.variant = 0, 0, 0, 0, 0
+    need = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc))
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=gpu)
+    out = torch.empty(f.shape[0], f.shape[2], *c.shape[1:4], device=gpu)
+    vp = ctypes.c_void_p
+    rc = L.mvhmr_unproject_forward(ctypes.byref(desc), vp(f.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(out.data_ptr()),
+                                   vp(ws.data_ptr()), ctypes.c_size_t(need), vp(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert float(np.abs(out.cpu().numpy() - d["out_softmax"]).max()) <= TOL
+
+
+def test_wrong_device_and_dtype_raise(gpu):
+    d = load_golden("unproj", "tiny_b2v2c4")
+    f, p, c = _dev(d, "features", gpu), _dev(d, "proj", gpu), _dev(d, "coords", gpu)
+    with pytest.raises(RuntimeError, match="expected all tensors on"):
+        aggregation.unprojection(f, p.cpu(), c)
+    with pytest.raises(RuntimeError, match="float32 or float16"):
+        aggregation.unprojection(f.double(), p, c)
+    with pytest.raises(ValueError, match="Unknown aggregation_method"):
+        aggregation.unprojection(f, p, c, aggregation_method="median")
