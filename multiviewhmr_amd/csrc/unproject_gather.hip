@@ -74,7 +74,8 @@ k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const
     __syncthreads();
 
     int q = cg * kGroupQuads + lane;
-    q = q < Q ? q : Q - 1;                                   // idle lanes shadow the last quad, never stored
+    const bool q_active = q < Q;
+    q = q_active ? q : Q - 1;                                // idle lanes shadow the last quad and write nothing
     const TF *fb = featT + (long long)b * V * mapsz + q * 4;
 
     for (int jj = 0; jj < kTileVox / 4; ++jj) {
@@ -108,7 +109,7 @@ k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const
 #pragma unroll
             for (int i = 0; i < 4; ++i) o.v[i] = ra[i].result(V);
         }
-        tile[j * tstride + lane] = o;
+        if (q_active) tile[j * tstride + lane] = o;
     }
     __syncthreads();
 
