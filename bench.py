@@ -135,34 +135,26 @@ def main():
     # planar (reference-contract) input: the step runs the layout pass, then the fused kernel on its result
     desc.feat_layout = _capi.LAYOUT_BVCHW
     variant = L.mvhmr_unproject_selected_variant(ctypes.byref(desc))
-    two_kernels = variant == _capi.VARIANT["gather"]
+    assert variant > 0, L.mvhmr_last_error().decode()
     vp = ctypes.c_void_p
     stream = vp(torch.cuda.current_stream(dev).cuda_stream)
-    if two_kernels:
-        featT = torch.empty(L.mvhmr_channels_last_bytes(ctypes.byref(desc)), dtype=torch.uint8, device=dev)
-        d_cl = _capi.Desc.from_buffer_copy(desc)
-        d_cl.feat_layout = _capi.LAYOUT_BVHWC
-        ws = None
-    else:
-        need = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc))
-        ws = torch.empty(max(need, 1), dtype=torch.uint8, device=dev)
+    # the step = layout pass (planar reference-contract input -> the layout the kernel reads) + fused kernel;
+    # they are launched through separate C-ABI calls so that HIP events can bracket each of them
+    lay = L.mvhmr_preferred_layout(ctypes.byref(desc))
+    conv = torch.empty(L.mvhmr_feature_layout_bytes(ctypes.byref(desc), lay), dtype=torch.uint8, device=dev)
+    d_k = _capi.Desc.from_buffer_copy(desc)
+    d_k.feat_layout = lay
 
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(3 * max(a.steps, 1))]
 
     def step(i=None):
         """one pass of the hot path; with i given, HIP events bracket the two kernels (same stream as the launches)"""
-        if two_kernels:
-            if i is not None: ev[3 * i].record()
-            _capi.check(L.mvhmr_features_to_channels_last(ctypes.byref(desc), vp(feats.data_ptr()), vp(featT.data_ptr()), stream))
-            if i is not None: ev[3 * i + 1].record()
-            _capi.check(L.mvhmr_unproject_forward(ctypes.byref(d_cl), vp(featT.data_ptr()), vp(proj.data_ptr()), vp(coords.data_ptr()),
-                                                  vp(out.data_ptr()), vp(0), 0, stream))
-            if i is not None: ev[3 * i + 2].record()
-        else:
-            if i is not None: ev[3 * i].record(); ev[3 * i + 1].record()
-            _capi.check(L.mvhmr_unproject_forward(ctypes.byref(desc), vp(feats.data_ptr()), vp(proj.data_ptr()), vp(coords.data_ptr()),
-                                                  vp(out.data_ptr()), vp(ws.data_ptr()), ws.numel(), stream))
-            if i is not None: ev[3 * i + 2].record()
+        if i is not None: ev[3 * i].record()
+        _capi.check(L.mvhmr_convert_features(ctypes.byref(desc), vp(feats.data_ptr()), lay, vp(conv.data_ptr()), stream))
+        if i is not None: ev[3 * i + 1].record()
+        _capi.check(L.mvhmr_unproject_forward(ctypes.byref(d_k), vp(conv.data_ptr()), vp(proj.data_ptr()), vp(coords.data_ptr()),
+                                              vp(out.data_ptr()), vp(0), 0, stream))
+        if i is not None: ev[3 * i + 2].record()
 
     def barrier():
         torch.cuda.synchronize()

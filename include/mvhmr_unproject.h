@@ -56,8 +56,10 @@ typedef enum mvhmr_dtype_t { MVHMR_F32 = 0, MVHMR_F16 = 1 } mvhmr_dtype_t;
 /* memory layout of `features` (and of `grad_features`) */
 typedef enum mvhmr_layout_t {
     MVHMR_LAYOUT_BVCHW = 0, /* (B,V,C,Hf,Wf) -- the reference's contract (aggregation.py:22-23, :191) */
-    MVHMR_LAYOUT_BVHWC = 1  /* (B,V,Hf,Wf,C) -- channels-last, what the kernels gather from; passing it
+    MVHMR_LAYOUT_BVHWC = 1, /* (B,V,Hf,Wf,C) -- channels-last, what the gather variant reads; passing it
                                skips the layout pass (e.g. a channels_last 1x1 conv upstream) */
+    MVHMR_LAYOUT_QUAD = 2   /* (B,V,C/4,Hf,Wf,4) -- "quad-planar", what the brick variant stages into LDS;
+                               only produced by mvhmr_convert_features (C % 4 == 0) */
 } mvhmr_layout_t;
 
 /* kernel selection; AUTO picks the fastest applicable one.  The others exist for tests and profiling. */
@@ -112,15 +114,17 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
                              size_t workspace_bytes, void *hip_stream);
 
 /*
- * Layout pass on its own: features (B,V,C,Hf,Wf) -> dst (B,V,Hf,Wf,C4) in desc->feat_dtype, C4 = C rounded up
- * to a multiple of 4 (padding channels are zero).  mvhmr_unproject_forward runs this internally into its
- * workspace when desc->feat_layout is MVHMR_LAYOUT_BVCHW; callers that keep the channels-last copy (or time
- * the two kernels separately) call it themselves and then pass MVHMR_LAYOUT_BVHWC.  dst needs
- * mvhmr_channels_last_bytes(desc) bytes.
+ * Layout pass on its own: features (B,V,C,Hf,Wf) -> dst in `dst_layout` (MVHMR_LAYOUT_BVHWC with the channel
+ * count rounded up to a multiple of 4 and zero padded, or MVHMR_LAYOUT_QUAD), desc->feat_dtype.
+ * mvhmr_unproject_forward runs the pass its kernel needs into its workspace when desc->feat_layout is
+ * MVHMR_LAYOUT_BVCHW; callers that keep the converted copy (or time the two kernels separately) call this and
+ * then pass desc->feat_layout = dst_layout.  mvhmr_preferred_layout says which layout the kernel that
+ * desc->variant selects reads; dst needs mvhmr_feature_layout_bytes(desc, dst_layout) bytes.
  */
-size_t mvhmr_channels_last_bytes(const mvhmr_unproject_desc *desc);
-int mvhmr_features_to_channels_last(const mvhmr_unproject_desc *desc, const void *features, void *dst,
-                                    void *hip_stream);
+int mvhmr_preferred_layout(const mvhmr_unproject_desc *desc);
+size_t mvhmr_feature_layout_bytes(const mvhmr_unproject_desc *desc, int dst_layout);
+int mvhmr_convert_features(const mvhmr_unproject_desc *desc, const void *features, int dst_layout, void *dst,
+                           void *hip_stream);
 
 /*
  * Caller-side helper of VolumeGenerator.forward (models/aggregation.py:138-187): fills

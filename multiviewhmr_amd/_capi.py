@@ -12,14 +12,14 @@ ABI_VERSION = 1
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH = range(5)
 AGG = {"softmax": 0, "sum": 1, "mean": 2, "max": 3}
 F32, F16 = 0, 1
-LAYOUT_BVCHW, LAYOUT_BVHWC = 0, 1
+LAYOUT_BVCHW, LAYOUT_BVHWC, LAYOUT_QUAD = 0, 1, 2
 VARIANT = {"auto": 0, "gather": 1, "brick": 2}
 
 EXPORTS = (
     "mvhmr_abi_version", "mvhmr_status_string", "mvhmr_last_error",
     "mvhmr_unproject_forward_workspace_bytes", "mvhmr_unproject_backward_workspace_bytes",
     "mvhmr_unproject_forward", "mvhmr_unproject_backward", "mvhmr_build_coord_volumes",
-    "mvhmr_unproject_selected_variant", "mvhmr_channels_last_bytes", "mvhmr_features_to_channels_last",
+    "mvhmr_unproject_selected_variant", "mvhmr_preferred_layout", "mvhmr_feature_layout_bytes", "mvhmr_convert_features",
 )
 
 
@@ -58,10 +58,12 @@ def lib():
     L.mvhmr_unproject_forward.argtypes = [dp, vp, vp, vp, vp, vp, sz, vp]
     L.mvhmr_unproject_backward.restype = ctypes.c_int
     L.mvhmr_unproject_backward.argtypes = [dp, vp, vp, vp, vp, vp, vp, sz, vp]
-    L.mvhmr_channels_last_bytes.restype = sz
-    L.mvhmr_channels_last_bytes.argtypes = [dp]
-    L.mvhmr_features_to_channels_last.restype = ctypes.c_int
-    L.mvhmr_features_to_channels_last.argtypes = [dp, vp, vp, vp]
+    L.mvhmr_preferred_layout.restype = ctypes.c_int
+    L.mvhmr_preferred_layout.argtypes = [dp]
+    L.mvhmr_feature_layout_bytes.restype = sz
+    L.mvhmr_feature_layout_bytes.argtypes = [dp, ctypes.c_int]
+    L.mvhmr_convert_features.restype = ctypes.c_int
+    L.mvhmr_convert_features.argtypes = [dp, vp, ctypes.c_int, vp, vp]
     L.mvhmr_build_coord_volumes.restype = ctypes.c_int
     L.mvhmr_build_coord_volumes.argtypes = [vp, vp, vp, i32, i32, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), vp]

@@ -39,7 +39,7 @@ int check_desc(const mvhmr_unproject_desc *d, Problem *p)
         return fail(MVHMR_ERR_INVALID_ARGUMENT, "Unknown aggregation_method: %d", d->method);
     if (d->feat_dtype < 0 || d->feat_dtype > MVHMR_F16 || d->out_dtype < 0 || d->out_dtype > MVHMR_F16)
         return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown dtype (feat %d, out %d)", d->feat_dtype, d->out_dtype);
-    if (d->feat_layout < 0 || d->feat_layout > MVHMR_LAYOUT_BVHWC) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown feature layout %d", d->feat_layout);
+    if (d->feat_layout < 0 || d->feat_layout > MVHMR_LAYOUT_QUAD) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown feature layout %d", d->feat_layout);
     if (d->variant < 0 || d->variant > MVHMR_VARIANT_BRICK) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", d->variant);
     if (d->views > kMaxViews) return fail(MVHMR_ERR_UNSUPPORTED, "at most %d views are supported (got %d)", kMaxViews, d->views);
     if (d->feat_dtype == MVHMR_F32 && d->out_dtype == MVHMR_F16)
@@ -53,8 +53,8 @@ int check_desc(const mvhmr_unproject_desc *d, Problem *p)
     p->out_f16 = d->out_dtype == MVHMR_F16;
     if ((long long)p->H * p->W * p->C4 >= (1ll << 31))
         return fail(MVHMR_ERR_UNSUPPORTED, "one feature map (Hf*Wf*C = %lld elements) exceeds 32-bit tap offsets", (long long)p->H * p->W * p->C4);
-    if (d->feat_layout == MVHMR_LAYOUT_BVHWC && p->C4 != p->C)
-        return fail(MVHMR_ERR_UNSUPPORTED, "channels-last features need C %% 4 == 0 (C = %d)", p->C);
+    if (d->feat_layout != MVHMR_LAYOUT_BVCHW && p->C4 != p->C)
+        return fail(MVHMR_ERR_UNSUPPORTED, "channels-last / quad-planar features need C %% 4 == 0 (C = %d)", p->C);
     return MVHMR_OK;
 }
 
@@ -62,10 +62,21 @@ size_t feat_elem(const Problem &p) { return p.feat_f16 ? 2 : 4; }
 size_t featT_bytes(const Problem &p) { return align_up((size_t)p.B * p.V * p.H * p.W * p.C4 * feat_elem(p)); }
 size_t gradT_bytes(const Problem &p) { return align_up((size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float)); }
 
+// which kernel runs: the layout the caller hands over decides when it is not the reference's planar one
 int pick_variant(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    if (d->variant == MVHMR_VARIANT_GATHER) return MVHMR_VARIANT_GATHER;
+    if (d->feat_layout == MVHMR_LAYOUT_BVHWC) return MVHMR_VARIANT_GATHER;
+    if (d->feat_layout == MVHMR_LAYOUT_QUAD) return MVHMR_VARIANT_BRICK;
+    if (d->variant != MVHMR_VARIANT_AUTO) return d->variant;
     return brick_supported(p) ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
+}
+
+int variant_conflict(const mvhmr_unproject_desc *d, const Problem &p, int variant)
+{
+    if (variant == MVHMR_VARIANT_BRICK && !brick_supported(p)) return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype");
+    if (d->variant != MVHMR_VARIANT_AUTO && d->variant != variant)
+        return fail(MVHMR_ERR_UNSUPPORTED, "feature layout %d cannot feed kernel variant %d", d->feat_layout, d->variant);
+    return MVHMR_OK;
 }
 
 // the gradient can be accumulated straight into grad_features when that already is fp32 channels-last
@@ -111,16 +122,16 @@ int mvhmr_unproject_selected_variant(const mvhmr_unproject_desc *desc)
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return -1;
-    if (desc->variant == MVHMR_VARIANT_BRICK && !brick_supported(p)) return -1;
-    return pick_variant(desc, p);
+    const int variant = pick_variant(desc, p);
+    return variant_conflict(desc, p, variant) == MVHMR_OK ? variant : -1;
 }
 
 size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc)
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
-    if (pick_variant(desc, p) == MVHMR_VARIANT_BRICK) return brick_workspace_bytes(p);
-    return desc->feat_layout == MVHMR_LAYOUT_BVCHW ? featT_bytes(p) : 0;
+    if (desc->feat_layout != MVHMR_LAYOUT_BVCHW) return 0;
+    return pick_variant(desc, p) == MVHMR_VARIANT_BRICK ? brick_workspace_bytes(p) : featT_bytes(p);
 }
 
 size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc)
@@ -141,13 +152,20 @@ int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *featur
     if (!features || !proj || !coords || !out) return fail(MVHMR_ERR_INVALID_ARGUMENT, "features / proj / coords / out must be non-null");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const int variant = pick_variant(desc, p);
-    if (desc->variant == MVHMR_VARIANT_BRICK && variant != MVHMR_VARIANT_BRICK)
-        return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape");
+    rc = variant_conflict(desc, p, variant);
+    if (rc != MVHMR_OK) return rc;
     rc = check_ws(workspace, workspace_bytes, mvhmr_unproject_forward_workspace_bytes(desc));
     if (rc != MVHMR_OK) return rc;
 
-    if (variant == MVHMR_VARIANT_BRICK)
-        return launched(launch_fwd_brick(features, desc->feat_layout == MVHMR_LAYOUT_BVHWC, proj, coords, out, workspace, p, s), "brick forward");
+    if (variant == MVHMR_VARIANT_BRICK) {
+        const void *featK = features;
+        if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) {
+            rc = launched(launch_to_quad_planar(features, workspace, p, s), "layout pass");
+            if (rc != MVHMR_OK) return rc;
+            featK = workspace;
+        }
+        return launched(launch_fwd_brick(featK, proj, coords, out, p, s), "brick forward");
+    }
 
     const void *featT = features;
     if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) {
@@ -166,6 +184,7 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
     if (rc != MVHMR_OK) return rc;
     if (!grad_out || !features || !proj || !coords || !grad_features)
         return fail(MVHMR_ERR_INVALID_ARGUMENT, "grad_out / features / proj / coords / grad_features must be non-null");
+    if (desc->feat_layout == MVHMR_LAYOUT_QUAD) return fail(MVHMR_ERR_UNSUPPORTED, "backward takes planar or channels-last features");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     rc = check_ws(workspace, workspace_bytes, mvhmr_unproject_backward_workspace_bytes(desc));
     if (rc != MVHMR_OK) return rc;
@@ -189,28 +208,43 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
     return launched(launch_grad_cast(gradT, grad_features, p, s), "gradient cast");
 }
 
-size_t mvhmr_channels_last_bytes(const mvhmr_unproject_desc *desc)
+int mvhmr_preferred_layout(const mvhmr_unproject_desc *desc)
 {
     Problem p;
-    mvhmr_unproject_desc d;
-    if (!desc) return 0;
-    d = *desc;
+    if (!desc) return -1;
+    mvhmr_unproject_desc d = *desc;
     d.feat_layout = MVHMR_LAYOUT_BVCHW;
-    if (check_desc(&d, &p) != MVHMR_OK) return 0;
-    return featT_bytes(p);
+    if (check_desc(&d, &p) != MVHMR_OK) return -1;
+    const int variant = pick_variant(&d, p);
+    if (variant_conflict(&d, p, variant) != MVHMR_OK) return -1;
+    return variant == MVHMR_VARIANT_BRICK ? MVHMR_LAYOUT_QUAD : MVHMR_LAYOUT_BVHWC;
 }
 
-int mvhmr_features_to_channels_last(const mvhmr_unproject_desc *desc, const void *features, void *dst, void *hip_stream)
+size_t mvhmr_feature_layout_bytes(const mvhmr_unproject_desc *desc, int dst_layout)
 {
     Problem p;
-    mvhmr_unproject_desc d;
+    if (!desc) return 0;
+    mvhmr_unproject_desc d = *desc;
+    d.feat_layout = MVHMR_LAYOUT_BVCHW;
+    if (check_desc(&d, &p) != MVHMR_OK) return 0;
+    if (dst_layout == MVHMR_LAYOUT_BVHWC) return featT_bytes(p);
+    if (dst_layout == MVHMR_LAYOUT_QUAD && p.C4 == p.C) return featT_bytes(p);
+    return 0;
+}
+
+int mvhmr_convert_features(const mvhmr_unproject_desc *desc, const void *features, int dst_layout, void *dst, void *hip_stream)
+{
+    Problem p;
     if (!desc) return fail(MVHMR_ERR_INVALID_ARGUMENT, "descriptor is null");
-    d = *desc;
+    mvhmr_unproject_desc d = *desc;
     d.feat_layout = MVHMR_LAYOUT_BVCHW;
     int rc = check_desc(&d, &p);
     if (rc != MVHMR_OK) return rc;
     if (!features || !dst) return fail(MVHMR_ERR_INVALID_ARGUMENT, "features / dst must be non-null");
-    return launched(launch_to_channels_last(features, dst, p, static_cast<hipStream_t>(hip_stream)), "layout pass");
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (dst_layout == MVHMR_LAYOUT_BVHWC) return launched(launch_to_channels_last(features, dst, p, s), "layout pass");
+    if (dst_layout == MVHMR_LAYOUT_QUAD) return launched(launch_to_quad_planar(features, dst, p, s), "layout pass");
+    return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown destination layout %d", dst_layout);
 }
 
 int mvhmr_build_coord_volumes(float *coords, const float *rot, const float *center, int32_t batch, int32_t volume_size,

@@ -28,6 +28,7 @@ constexpr int kMaxViews = 16;   // per-voxel view records kept in LDS / register
 struct Taps {
     int x0, y0, x1, y1;          // clamped to [0, W-1] / [0, H-1]
     float w00, w01, w10, w11;    // (y0,x0) (y0,x1) (y1,x0) (y1,x1) = nw, ne, sw, se
+    int rx0, ry0;                // unclamped nw tap, in [-1, W-1] x [-1, H-1] (0,0 when any == 0)
     int any;
 };
 
@@ -39,6 +40,7 @@ __device__ __forceinline__ Taps make_taps(const float *__restrict__ P, float X0,
     Taps t;
     t.x0 = t.y0 = t.x1 = t.y1 = 0;
     t.w00 = t.w01 = t.w10 = t.w11 = 0.f;
+    t.rx0 = t.ry0 = 0;
     t.any = 0;
     if (!(z > 0.f)) return t;                        // z <= 0 (or NaN): sample is exactly 0
     const float u = __fdiv_rn(a, z), v = __fdiv_rn(b, z);
@@ -61,6 +63,8 @@ __device__ __forceinline__ Taps make_taps(const float *__restrict__ P, float X0,
     t.y0 = yin0 ? y0 : 0;
     t.x1 = xin1 ? x1 : W - 1;
     t.y1 = yin1 ? y1 : H - 1;
+    t.rx0 = x0;
+    t.ry0 = y0;
     t.any = 1;
     return t;
 }

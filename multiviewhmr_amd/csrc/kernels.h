@@ -31,8 +31,9 @@ hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const floa
 // brick variant (LDS-staged patches); returns hipErrorNotSupported when the shape does not qualify
 bool brick_supported(const Problem &p);
 size_t brick_workspace_bytes(const Problem &p);
-hipError_t launch_fwd_brick(const void *features, bool channels_last_in, const float *proj, const float *coords,
-                            void *out, void *workspace, const Problem &p, hipStream_t s);
+hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, hipStream_t s);
+hipError_t launch_fwd_brick(const void *featK, const float *proj, const float *coords, void *out, const Problem &p,
+                            hipStream_t s);
 
 hipError_t launch_build_coords(float *coords, const float *rot, const float *center, int B, int S,
                                const double pos[3], const double sides[3], hipStream_t s);

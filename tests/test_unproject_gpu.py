@@ -15,11 +15,18 @@ from oracle import cport
 pytestmark = pytest.mark.gpu
 MODES = ("softmax", "sum", "mean", "max")
 TOL = 1e-4                      # fp32 bar from BASELINE.json
-VARIANTS = ("gather", "auto")
+VARIANTS = ("gather", "auto", "brick")
 
 
 def _dev(d, key, gpu, dtype=torch.float32):
     return torch.from_numpy(d[key]).to(device=gpu, dtype=dtype)
+
+
+def _brick_ok(f, c):
+    """shapes the brick variant takes: fp32, V in {2,4,8}, C % 4 == 0, volume divisible into 4 x 8 x 32 bricks"""
+    X, Y, Z = c.shape[1:4]
+    return (f.dtype == torch.float32 and f.shape[1] in (2, 4, 8) and f.shape[2] % 4 == 0
+            and X % 4 == 0 and Y % 8 == 0 and Z % 32 == 0)
 
 
 def _scale(ref):
@@ -32,6 +39,10 @@ def _scale(ref):
 def test_forward_matches_reference_goldens(case, variant, gpu):
     d = load_golden("unproj", case)
     f, p, c = _dev(d, "features", gpu), _dev(d, "proj", gpu), _dev(d, "coords", gpu)
+    if variant == "brick" and not _brick_ok(f, c):
+        with pytest.raises(RuntimeError, match="brick variant does not support"):
+            aggregation.unprojection(f, p, c, variant="brick")
+        return
     for mode in MODES:
         if "out_" + mode not in d:
             continue
@@ -113,6 +124,40 @@ def test_forward_and_backward_vs_oracle(shape, mode, gpu):
     out.backward(torch.from_numpy(go).to(gpu))
     gref = cport.backward(go, feats, proj, coords, mode)
     assert float(np.abs(f.grad.cpu().numpy() - gref).max()) <= TOL * max(1.0, float(np.abs(gref).max()) / 8.0)
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=2, V=4, C=32, H=48, W=48, vol=(8, 16, 32)),        # several bricks per sample, windows inside the maps
+    dict(B=1, V=2, C=8, H=24, W=24, vol=(4, 8, 64)),          # two z bricks per column
+    dict(B=1, V=8, C=12, H=32, W=32, vol=(4, 8, 32)),         # 8 views
+    dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)),        # huge maps: the brick's taps overflow the LDS window -> global fallback
+    dict(B=1, V=4, C=16, H=12, W=12, vol=(8, 8, 32)),         # tiny maps: most taps fall outside the image (zero padding)
+])
+@pytest.mark.parametrize("mode", MODES)
+def test_brick_variant_vs_oracle(shape, mode, gpu):
+    feats, proj, coords = _ring_problem(seed=7 + MODES.index(mode), **shape)
+    f, p, c = torch.from_numpy(feats).to(gpu), torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    assert _brick_ok(f, c)
+    out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick")
+    ref = cport.forward(feats, proj, coords, mode)
+    assert float(np.abs(out.cpu().numpy() - ref).max()) <= TOL
+    assert torch.equal(out, aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick"))   # deterministic
+    gat = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="gather")
+    assert float((out - gat).abs().max()) <= 2e-6         # same arithmetic, two kernels
+
+
+def test_brick_variant_with_cameras_inside_the_volume(gpu):
+    """adversarial geometry for the window logic: behind-camera voxels, bricks with no valid voxel for a view"""
+    d = load_golden("unproj", "adversarial_v4c6")
+    rng = np.random.default_rng(0)
+    feats = rng.standard_normal((1, 4, 8, 16, 16), dtype=np.float32)
+    g = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(32), indexing="ij"), -1).astype(np.float32)
+    coords = (-1250.0 + g * np.array([2500.0 / 7, 2500.0 / 7, 2500.0 / 31], np.float32))[None]
+    f, p, c = torch.from_numpy(feats).to(gpu), _dev(d, "proj", gpu), torch.from_numpy(coords).to(gpu)
+    for mode in MODES:
+        out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick")
+        ref = cport.forward(feats, d["proj"], coords, mode)
+        assert float(np.abs(out.cpu().numpy() - ref).max()) <= TOL
 
 
 def test_channels_last_features_skip_the_layout_pass(gpu):
