@@ -34,6 +34,8 @@ namespace mvhmr {
 constexpr int kBZ = 32;            // z extent of a brick: 128-B output runs
 constexpr int kBX = 4;
 constexpr int kMaxChunks = 5;      // 64-slot DMA chunks per wave per quad
+constexpr int kZeroSlots = 128;    // always-zero 16-B slots at the head of every ring buffer (row stride <= 126)
+constexpr int kZeroBytes = kZeroSlots * 16;
 
 // workgroup barrier that waits for this wave's LDS operations only (not for global loads / stores in flight)
 __device__ __forceinline__ void lds_barrier()
@@ -42,6 +44,48 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+
+// LDS-DMA of 16 B per lane: lane l's bytes land at lds_dst + 16*l (lds_dst wave-uniform), read from base + voff[l].
+// Written as inline asm on purpose: hipcc tracks the builtin form as a pending LDS write and puts s_waitcnt vmcnt(0)
+// in front of every later ds_read, which drains the whole ring and the output stores each quad.  The asm form is
+// outside its bookkeeping; completion is counted by hand (wait_vmcnt) before the barrier that precedes the reads.
+__device__ __forceinline__ void glds16(const void *base, unsigned voff, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(voff), "s"(base), "s"(lds_dst)
+                 : "memory");
+}
+
+__device__ __forceinline__ f32x4 lds_tap(const unsigned char *smem, int addr)
+{
+    const float4 t = *reinterpret_cast<const float4 *>(smem + addr);
+    return f32x4{{t.x, t.y, t.z, t.w}};
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n: wait until at most n vector-memory operations of this wave
+// (loads, LDS-DMA and stores count together, in issue order) are still outstanding
+__device__ __forceinline__ void wait_vmcnt(int n)
+{
+    switch (uniform(n)) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
 
 template <int VT>
 struct BrickShared {
@@ -75,17 +119,16 @@ k_to_quad_planar(const float *__restrict__ src, float4 *__restrict__ dst, int C,
 }
 
 // NT threads, brick = 4 x (NT/128) x 32 voxels, one voxel per lane.
-// LDS: [ buffer 0 | buffer 1 | BrickShared ], each buffer = 64 B of zeros + `cap` 16-B slots shared by the views.
+// LDS: [ ring of 2 or 3 buffers | BrickShared ]; a buffer = a zero region + the views' windows, 16-B slots.
 template <int METHOD, int VT, int NT>
 __global__ void __launch_bounds__(NT)
 k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, const float *__restrict__ coords,
             float *__restrict__ out, int C, int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample,
-            int cap, int total_blocks)
+            int lds_slots, int total_blocks)
 {
     constexpr int BY = NT / 128, NW = NT / 64;
     extern __shared__ __align__(16) unsigned char smem[];
-    const int buf_bytes = 64 + cap * 16;
-    BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + 2 * buf_bytes);
+    BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_slots * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
 
     // XCD-aware order: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous
@@ -100,7 +143,6 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
 
     if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = proj[((long long)b * VT) * 12 + tid];
     if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
-    if (tid < 8) *reinterpret_cast<float4 *>(smem + (tid >> 2) * buf_bytes + (tid & 3) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     // ---- this lane's voxel and its tap records (once per brick)
@@ -133,7 +175,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     // ---- window per view (block-uniform): origin, width, odd row stride, rows, first slot; views packed back to back
     int wx0[VT], wy0[VT], ws[VT], nch[VT + 1], slot0[VT];
     nch[0] = 0;
-    int used = 0;
+    int used = 0, max_stride = 0;
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
         const int xmin = uniform(sh->bbox[v][0]), ymin = uniform(sh->bbox[v][1]);
@@ -145,31 +187,44 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         const int stride = bw | 1;
         const int chunks = (stride * bh + 63) >> 6;                              // 64-slot DMA chunks
         wx0[v] = xmin; wy0[v] = ymin; ws[v] = stride;
+        max_stride = stride > max_stride ? stride : max_stride;
         slot0[v] = used;
         used += chunks << 6;
         nch[v + 1] = nch[v] + chunks;
     }
-    const bool fits = used <= cap && nch[VT] <= kMaxChunks * NW;
+    // ring depth: 3 buffers (DMA two quads ahead) when the windows fit a third of the pool, else 2, else no LDS
+    const int cap3 = ((lds_slots - 3 * kZeroSlots) / 3) & ~63, cap2 = ((lds_slots - 2 * kZeroSlots) / 2) & ~63;
+    const int nb = used <= cap3 ? 3 : 2;
+    const int cap = nb == 3 ? cap3 : cap2;
+    const int buf_bytes = kZeroBytes + cap * 16;                               // zero region + the pooled windows
+    const bool fits = used <= cap && nch[VT] <= kMaxChunks * NW && max_stride + 2 <= kZeroSlots;
     float *const obase = out + (long long)b * C * N;
     const float4 *const fk = featK + (long long)b * VT * nq * HW;                  // this sample's quad planes
 
     if (fits) {
-        // ---- LDS byte offsets (inside a buffer) of the two tap rows of every view
-        int a0[VT], a1[VT];
+        for (int i = tid; i < kZeroSlots * nb; i += NT)
+            *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        // ---- LDS byte offset (inside a buffer) of the nw tap of every view; the sw tap is one row stride further.
+        // A sample that is identically zero (!ok: weights 0) reads the zero region at the head of the buffer, which is
+        // long enough to hold "one row further" for every admissible stride.
+        int a0[VT], ws16[VT];
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             const bool ok = (valid >> v) & 1u;
             const int s0 = slot0[v] + (ty[v] - wy0[v]) * ws[v] + (tx[v] - wx0[v]);
-            a0[v] = ok ? 64 + s0 * 16 : 0;                                       // !ok: weights are 0, read the zero slots
-            a1[v] = ok ? a0[v] + ws[v] * 16 : 0;
+            a0[v] = ok ? kZeroBytes + s0 * 16 : 0;
+            ws16[v] = ws[v] * 16;
         }
+        const unsigned voxb = vox * 4u;
         // ---- DMA chunks of this wave: chunk c covers 64 consecutive slots of one view's window
-        int g_idx[kMaxChunks], l_dst[kMaxChunks];
+        unsigned g_off[kMaxChunks];                                              // byte offset inside the sample's quad plane set
+        int l_dst[kMaxChunks];
+        int n_c = 0;                                                             // chunks this wave issues per quad
 #pragma unroll
         for (int r = 0; r < kMaxChunks; ++r) {
             const int c = wave + r * NW;
             l_dst[r] = -1;
-            g_idx[r] = 0;
+            g_off[r] = 0;
             if (c < nch[VT]) {
                 int v = 0;
 #pragma unroll
@@ -182,43 +237,74 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 int gx = ox + px, gy = oy + py;                                  // pad column / rows past the window / outside the
                 gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);                     // image: clamp -- those slots only meet zero weights
                 gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-                g_idx[r] = (v * nq) * HW + gy * W + gx;
-                l_dst[r] = 64 + (s0 + (j << 6)) * 16;
+                g_off[r] = (unsigned)((v * nq) * HW + gy * W + gx) * 16u;
+                l_dst[r] = kZeroBytes + (s0 + (j << 6)) * 16;
+                ++n_c;
             }
         }
+        const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;           // LDS byte address of the ring
+        auto ring = [&](int q) { return (nb == 3 ? q % 3 : q & 1) * buf_bytes; };
         auto dma = [&](int q) {
             const float4 *src = fk + (long long)q * HW;
-            const int boff = (q & 1) * buf_bytes;
+            const int boff = ring(q);
 #pragma unroll
             for (int r = 0; r < kMaxChunks; ++r)
-                if (l_dst[r] >= 0)
-                    __builtin_amdgcn_global_load_lds((const void *)(src + g_idx[r]), (lds_void_t *)(smem + uniform(l_dst[r] + boff)), 16, 0, 0);
+                if (l_dst[r] >= 0) glds16(src, g_off[r], lds_base + (unsigned)uniform(l_dst[r] + boff));
         };
-        auto tap = [&](int addr) -> f32x4 {
-            const float4 t = *reinterpret_cast<const float4 *>(smem + addr);
-            return f32x4{{t.x, t.y, t.z, t.w}};
+        // ---- channel-quad loop, software-pipelined inside every wave (ring of nb LDS buffers):
+        //   iteration q, once per view u:
+        //                 issue the 4 ds_read_b128 of view u, quad q+1  (its buffer was completed by the last barrier)
+        //                 cross-view aggregate + stores of quad q       (VALU work that covers the LDS latency)
+        //                 bilinear fma of view u, quad q+1 -> sn        (first use of the reads)
+        //   then          issue the DMA of quad q+nb                    (into the buffer quad q used)
+        //                 retire this wave's DMA of quad q+2, barrier
+        // The barrier orders LDS traffic only; the counted vmcnt leaves younger DMAs and the output stores in flight.
+        // Register budget (128 VGPRs at 16 waves/CU, and NO spills: a scratch access is a vector-memory operation and
+        // would break the counted vmcnt waits below -- the Makefile fails the build if this kernel uses scratch):
+        // one view's taps (4 x b128) are in flight at a time; sub-step u reads view u of quad q+1, aggregates and
+        // stores its share of quad q's channels meanwhile, then folds the taps into the next quad's samples.
+        f32x4 T[4];
+        float s[4][VT], sn[4][VT];                                               // samples of quad q / of quad q+1
+        auto read_view = [&](int q, int v) {
+            const int base = a0[v] + ring(q), row1 = base + ws16[v];
+            T[0] = lds_tap(smem, base); T[1] = lds_tap(smem, base + 16);
+            T[2] = lds_tap(smem, row1); T[3] = lds_tap(smem, row1 + 16);
+        };
+        auto bilerp_view = [&](int v) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sn[i][v] = bilerp(T[0].v[i], T[1].v[i], T[2].v[i], T[3].v[i], w00[v], w01[v], w10[v], w11[v]);
+        };
+        auto reduce_store = [&](int q, int c) {                                  // channel c of quad q
+            float *oc = obase + (long long)(q * 4 + c) * N;
+            *reinterpret_cast<float *>(reinterpret_cast<char *>(oc) + voxb) = aggregate<METHOD, VT>(s[c]);
         };
 
-        // ---- channel-quad loop: dma(q+1) | sample(q) | wait for dma(q+1) | barrier
-        // The barrier orders LDS traffic only; a counted vmcnt leaves this quad's 4 output stores in flight
-        // (a __syncthreads() here would drain vmcnt: every wave waiting for its stores 64 times per brick).
-        dma(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int q = 0; q < nb && q < nq; ++q) dma(q);
+        wait_vmcnt(nb == 3 && nq > 2 ? n_c : 0);                                 // quads 0 and 1 have landed
         lds_barrier();
+#pragma unroll
+        for (int v = 0; v < VT; ++v) { read_view(0, v); bilerp_view(v); }
+        lds_barrier();                       // every wave is done with quad 0's buffer before anyone's DMA reuses it
+#pragma nounroll
         for (int q = 0; q < nq; ++q) {
-            if (q + 1 < nq) dma(q + 1);
-            const int boff = (q & 1) * buf_bytes;
-            float s[4][VT];
+            const bool more = q + 1 < nq;
 #pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                const f32x4 a = tap(a0[v] + boff), bb = tap(a0[v] + boff + 16), c = tap(a1[v] + boff), d = tap(a1[v] + boff + 16);
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s[i][v] = bilerp(a.v[i], bb.v[i], c.v[i], d.v[i], w00[v], w01[v], w10[v], w11[v]);
+                for (int v = 0; v < VT; ++v) s[i][v] = sn[i][v];
+#pragma unroll
+            for (int u = 0; u < VT; ++u) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) read_view(q + 1, u);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = (4 * u) / VT; c < (4 * (u + 1)) / VT; ++c) reduce_store(q, c);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) bilerp_view(u);
             }
-            float *oq = obase + (long long)(q * 4) * N;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) (oq + i * N)[vox] = aggregate<METHOD, VT>(s[i]);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            const bool issue = q + nb < nq;
+            if (issue) dma(q + nb);
+            if (q + 2 < nq) wait_vmcnt(nb == 3 ? 4 + (issue ? n_c : 0) : 0);
             lds_barrier();
         }
     } else {
@@ -254,29 +340,21 @@ namespace {
 constexpr int kNT = 1024;                             // 1024 voxels per brick: 4 x 8 x 32
 constexpr int kBYv = kNT / 128;
 
-int pick_cap()
-{
-    // two buffers of (64 B zeros + cap 16-B slots) + BrickShared must fit 160 KiB (one block per CU);
-    // a block stages at most kMaxChunks * NW chunks of 64 slots per quad
-    const int budget = (160 * 1024 - 1024) / 2 - 64;
-    int cap = budget / 16;
-    const int most = kMaxChunks * (kNT / 64) * 64;
-    cap = cap < most ? cap : most;
-    return cap & ~63;
-}
+// 16-B LDS slots the ring may use: everything but BrickShared (one block per CU owns all 160 KiB)
+int pick_lds_slots() { return (160 * 1024 - 1024) / 16; }
 
 template <int METHOD, int VT>
 hipError_t launch_v(const float4 *featK, const float *proj, const float *coords, float *out, const Problem &p, hipStream_t s)
 {
     const int nbx = p.X / kBX, nby = p.Y / kBYv, nbz = p.Z / kBZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
-    const int cap = pick_cap();
-    const size_t lds = 2 * (64 + (size_t)cap * 16) + sizeof(BrickShared<VT>);
+    const int slots = pick_lds_slots();
+    const size_t lds = (size_t)slots * 16 + sizeof(BrickShared<VT>);
     auto kern = k_fwd_brick<METHOD, VT, kNT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     const int grid = (total + 7) / 8 * 8;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, cap, total);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total);
     return hipGetLastError();
 }
 
@@ -286,7 +364,6 @@ hipError_t launch_m(const float4 *featK, const float *proj, const float *coords,
     switch (p.V) {
     case 2: return launch_v<METHOD, 2>(featK, proj, coords, out, p, s);
     case 4: return launch_v<METHOD, 4>(featK, proj, coords, out, p, s);
-    case 8: return launch_v<METHOD, 8>(featK, proj, coords, out, p, s);
     }
     return hipErrorNotSupported;
 }
@@ -295,7 +372,7 @@ hipError_t launch_m(const float4 *featK, const float *proj, const float *coords,
 bool brick_supported(const Problem &p)
 {
     if (p.feat_f16 || p.out_f16) return false;                            // fp32 storage only (for now)
-    if (p.V != 2 && p.V != 4 && p.V != 8) return false;
+    if (p.V != 2 && p.V != 4) return false;                               // 8 views: does not fit 128 VGPRs yet -> gather
     if (p.C % 4 || p.Z % kBZ || p.X % kBX || p.Y % kBYv) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
     if (p.N >= (1ll << 30)) return false;                                 // 32-bit voxel offsets in the stores

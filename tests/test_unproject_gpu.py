@@ -23,9 +23,9 @@ def _dev(d, key, gpu, dtype=torch.float32):
 
 
 def _brick_ok(f, c):
-    """shapes the brick variant takes: fp32, V in {2,4,8}, C % 4 == 0, volume divisible into 4 x 8 x 32 bricks"""
+    """shapes the brick variant takes: fp32, V in {2,4}, C % 4 == 0, volume divisible into 4 x 8 x 32 bricks"""
     X, Y, Z = c.shape[1:4]
-    return (f.dtype == torch.float32 and f.shape[1] in (2, 4, 8) and f.shape[2] % 4 == 0
+    return (f.dtype == torch.float32 and f.shape[1] in (2, 4) and f.shape[2] % 4 == 0
             and X % 4 == 0 and Y % 8 == 0 and Z % 32 == 0)
 
 
@@ -129,7 +129,7 @@ def test_forward_and_backward_vs_oracle(shape, mode, gpu):
 @pytest.mark.parametrize("shape", [
     dict(B=2, V=4, C=32, H=48, W=48, vol=(8, 16, 32)),        # several bricks per sample, windows inside the maps
     dict(B=1, V=2, C=8, H=24, W=24, vol=(4, 8, 64)),          # two z bricks per column
-    dict(B=1, V=8, C=12, H=32, W=32, vol=(4, 8, 32)),         # 8 views
+    dict(B=1, V=2, C=12, H=32, W=32, vol=(4, 8, 32)),         # odd number of quads
     dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)),        # huge maps: the brick's taps overflow the LDS window -> global fallback
     dict(B=1, V=4, C=16, H=12, W=12, vol=(8, 8, 32)),         # tiny maps: most taps fall outside the image (zero padding)
 ])
