@@ -147,7 +147,12 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
 
     // ---- this lane's voxel and its tap records (once per brick)
     const int col = wave * 2 + (lane >> 5);
-    const int vx = kx * kBX + (col & 3), vy = ky * BY + (col >> 2), vz = kz * kBZ + (lane & 31);
+    // z of this lane inside the brick: the four 16-lane groups ds_read_b128 services one after the other are
+    // {0-3,12-15,20-27}, {4-11,16-19,28-31} and the same +32; give each of them 16 CONSECUTIVE z so that a group spans
+    // ~23 window rows instead of ~40 (fewer slot collisions); the 32 lanes still fill one 128-B run of every store
+    const int l5 = lane & 31;
+    const int zin = l5 < 4 ? l5 : l5 < 12 ? 12 + l5 : l5 < 16 ? l5 - 8 : l5 < 20 ? 8 + l5 : l5 < 28 ? l5 - 12 : l5;
+    const int vx = kx * kBX + (col & 3), vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
     const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);              // N < 2^30 (brick_supported)
     float w00[VT], w01[VT], w10[VT], w11[VT];
     int tx[VT], ty[VT];
@@ -264,48 +269,52 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // one view's taps (4 x b128) are in flight at a time; sub-step u reads view u of quad q+1, aggregates and
         // stores its share of quad q's channels meanwhile, then folds the taps into the next quad's samples.
         f32x4 T[4];
-        float s[4][VT], sn[4][VT];                                               // samples of quad q / of quad q+1
+        float sA[4][VT], sB[4][VT];                                              // samples of the quad being reduced / being built
         auto read_view = [&](int q, int v) {
             const int base = a0[v] + ring(q), row1 = base + ws16[v];
             T[0] = lds_tap(smem, base); T[1] = lds_tap(smem, base + 16);
             T[2] = lds_tap(smem, row1); T[3] = lds_tap(smem, row1 + 16);
         };
-        auto bilerp_view = [&](int v) {
+        auto bilerp_view = [&](float (&sn)[4][VT], int v) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) sn[i][v] = bilerp(T[0].v[i], T[1].v[i], T[2].v[i], T[3].v[i], w00[v], w01[v], w10[v], w11[v]);
         };
-        auto reduce_store = [&](int q, int c) {                                  // channel c of quad q
-            float *oc = obase + (long long)(q * 4 + c) * N;
-            *reinterpret_cast<float *>(reinterpret_cast<char *>(oc) + voxb) = aggregate<METHOD, VT>(s[c]);
+        // stores go through a buffer descriptor rebuilt per quad from wave-uniform values: base = this sample's quad q,
+        // scalar offset = channel * N * 4, lane offset = voxel * 4 -- no per-lane 64-bit address arithmetic
+        const unsigned chan_bytes = (unsigned)(N * 4);
+        auto reduce_store = [&](const float (&sc)[4][VT], __amdgpu_buffer_rsrc_t rs, int c) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, aggregate<METHOD, VT>(sc[c])), rs, (int)voxb, (int)(c * chan_bytes), 0);
         };
-
-        for (int q = 0; q < nb && q < nq; ++q) dma(q);
-        wait_vmcnt(nb == 3 && nq > 2 ? n_c : 0);                                 // quads 0 and 1 have landed
-        lds_barrier();
-#pragma unroll
-        for (int v = 0; v < VT; ++v) { read_view(0, v); bilerp_view(v); }
-        lds_barrier();                       // every wave is done with quad 0's buffer before anyone's DMA reuses it
-#pragma nounroll
-        for (int q = 0; q < nq; ++q) {
+        // one quad: reduce + store quad q from sc while the taps of quad q+1 are read and folded into sn
+        auto quad_step = [&](int q, const float (&sc)[4][VT], float (&sn)[4][VT]) {
             const bool more = q + 1 < nq;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int v = 0; v < VT; ++v) s[i][v] = sn[i][v];
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
 #pragma unroll
             for (int u = 0; u < VT; ++u) {
                 __builtin_amdgcn_sched_barrier(0);
                 if (more) read_view(q + 1, u);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int c = (4 * u) / VT; c < (4 * (u + 1)) / VT; ++c) reduce_store(q, c);
+                for (int c = (4 * u) / VT; c < (4 * (u + 1)) / VT; ++c) reduce_store(sc, rs, c);
                 __builtin_amdgcn_sched_barrier(0);
-                if (more) bilerp_view(u);
+                if (more) bilerp_view(sn, u);
             }
             const bool issue = q + nb < nq;
             if (issue) dma(q + nb);
             if (q + 2 < nq) wait_vmcnt(nb == 3 ? 4 + (issue ? n_c : 0) : 0);
             lds_barrier();
+        };
+
+        for (int q = 0; q < nb && q < nq; ++q) dma(q);
+        wait_vmcnt(nb == 3 && nq > 2 ? n_c : 0);                                 // quads 0 and 1 have landed
+        lds_barrier();
+#pragma unroll
+        for (int v = 0; v < VT; ++v) { read_view(0, v); bilerp_view(sA, v); }
+        lds_barrier();                       // every wave is done with quad 0's buffer before anyone's DMA reuses it
+#pragma nounroll
+        for (int q = 0; q < nq; q += 2) {                                        // ping-pong: no copies between the two sample sets
+            quad_step(q, sA, sB);
+            if (q + 1 < nq) quad_step(q + 1, sB, sA);
         }
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (clamped taps, zero weights outside)
@@ -375,7 +384,7 @@ bool brick_supported(const Problem &p)
     if (p.V != 2 && p.V != 4) return false;                               // 8 views: does not fit 128 VGPRs yet -> gather
     if (p.C % 4 || p.Z % kBZ || p.X % kBX || p.Y % kBYv) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
-    if (p.N >= (1ll << 30)) return false;                                 // 32-bit voxel offsets in the stores
+    if (p.N >= (1ll << 28)) return false;                                 // 32-bit byte offsets inside one quad of the output
     return true;
 }
 
