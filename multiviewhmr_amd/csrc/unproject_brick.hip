@@ -291,12 +291,9 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
 #pragma unroll
             for (int u = 0; u < VT; ++u) {
-                __builtin_amdgcn_sched_barrier(0);
                 if (more) read_view(q + 1, u);
-                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int c = (4 * u) / VT; c < (4 * (u + 1)) / VT; ++c) reduce_store(sc, rs, c);
-                __builtin_amdgcn_sched_barrier(0);
                 if (more) bilerp_view(sn, u);
             }
             const bool issue = q + nb < nq;
