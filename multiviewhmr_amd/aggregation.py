@@ -158,15 +158,18 @@ def feature_level_projections(cameras, images_shape, features_shape):
     new_width, new_height = features_shape
     sx, sy = new_width / width, new_height / height
     V, B = len(cameras), len(cameras[0])
-    out = np.empty((B, V, 3, 4), dtype=np.float32)
-    for v in range(V):
-        for b in range(B):
-            cam = cameras[v][b]
-            K = np.array(cam.K, dtype=np.float64, copy=True)
-            K[0, 0], K[1, 1] = K[0, 0] * sx, K[1, 1] * sy
-            K[0, 2], K[1, 2] = K[0, 2] * sx, K[1, 2] * sy
-            out[b, v] = K.dot(np.hstack([cam.R, cam.t]))
-    return out
+    # one pass over the Python objects, then batched float64 math (same operations, same order as Camera does them)
+    K = np.array([[cameras[v][b].K for v in range(V)] for b in range(B)], dtype=np.float64)          # (B,V,3,3), a copy
+    Rt = np.array([[np.hstack([cameras[v][b].R, cameras[v][b].t]) for v in range(V)] for b in range(B)], dtype=np.float64)
+    K[..., 0, 0] = K[..., 0, 0] * sx
+    K[..., 1, 1] = K[..., 1, 1] * sy
+    K[..., 0, 2] = K[..., 0, 2] * sx
+    K[..., 1, 2] = K[..., 1, 2] * sy
+    # K.dot([R|t]) per camera: spelled as the same k-ordered sum of products numpy's 3x3 @ 3x4 dot performs
+    P = K[..., :, 0:1] * Rt[..., 0:1, :]
+    P = P + K[..., :, 1:2] * Rt[..., 1:2, :]
+    P = P + K[..., :, 2:3] * Rt[..., 2:3, :]
+    return P.astype(np.float32)
 
 
 class VolumeGenerator(nn.Module):
