@@ -319,3 +319,81 @@ def test_wrong_device_and_dtype_raise(gpu):
         aggregation.unprojection(f.double(), p, c)
     with pytest.raises(ValueError, match="Unknown aggregation_method"):
         aggregation.unprojection(f, p, c, aggregation_method="median")
+
+
+# ------------------------------------------------------------------------------------ BASELINE configs[2..4] at full per-GPU size
+def _oracle_on_channels(f, p, c, out, chans, b, mode="softmax"):
+    """channels are independent: check a few of them (one sample) against the CPU oracle"""
+    fs = f[b:b + 1, :, chans].float().cpu().numpy()
+    ref = cport.forward(fs, p[b:b + 1].cpu().numpy(), c[b:b + 1].cpu().numpy(), mode)
+    return float(np.abs(out[b:b + 1, chans].float().cpu().numpy() - ref).max()), ref
+
+
+def test_config2_fp16_forward_backward_full_size(gpu):
+    """configs[2]: 64^3 grid, 4 views, 256 ch, batch 32, fp16 storage, forward + backward."""
+    torch.manual_seed(2)
+    B, V, C, H, S = 32, 4, 256, 96, 64
+    _, proj, coords = _ring_problem(B=1, V=V, C=1, H=H, W=H, vol=(S, S, S), seed=2, theta=0.0)
+    f = torch.randn(B, V, C, H, H, device=gpu, dtype=torch.float16).requires_grad_(True)
+    p = torch.from_numpy(proj).to(gpu).expand(B, -1, -1, -1).contiguous()
+    c = torch.from_numpy(coords).to(gpu).expand(B, -1, -1, -1, -1).contiguous()
+    out = aggregation.unprojection(f, p, c)
+    assert out.dtype == torch.float16 and tuple(out.shape) == (B, C, S, S, S)
+    chans = [0, 1, 127, 255]
+    err, ref = _oracle_on_channels(f.detach(), p, c, out.detach(), chans, b=31)
+    assert err <= TOL + np.abs(ref).max() * 2.0 ** -11
+    # backward: gradient of sum(out * g) for a sparse g touches every code path; check it on a channel slice
+    g = torch.zeros_like(out)
+    g[31, chans] = torch.randn(len(chans), S, S, S, device=gpu, dtype=torch.float16)
+    out.backward(g)
+    assert f.grad.dtype == torch.float16 and bool(torch.isfinite(f.grad).all())
+    gref = cport.backward(g[31:32, chans].float().cpu().numpy(), f[31:32, :, chans].detach().float().cpu().numpy(),
+                          proj, coords, "softmax")
+    got = f.grad[31:32, :, chans].float().cpu().numpy()
+    assert float(np.abs(got - gref).max()) <= TOL + np.abs(gref).max() * 2.0 ** -10
+    assert float(f.grad[:31].abs().max()) == 0.0 and float(f.grad[31, :, 2:127].abs().max()) == 0.0   # nothing leaks across samples / channels
+    del out, g, f
+    torch.cuda.empty_cache()
+
+
+def test_config3_eight_views_per_gpu_shard(gpu):
+    """configs[3]: 64^3 grid, 8 views (MPI-INF-like ring), 256 ch, batch 64 over 4 GPUs = 16 samples per GPU."""
+    torch.manual_seed(3)
+    B, V, C, H, S = 16, 8, 256, 96, 64
+    _, proj, coords = _ring_problem(B=1, V=V, C=1, H=H, W=H, vol=(S, S, S), seed=3, theta=0.0)
+    f = torch.randn(B, V, C, H, H, device=gpu)
+    p = torch.from_numpy(proj).to(gpu).expand(B, -1, -1, -1).contiguous()
+    c = torch.from_numpy(coords).to(gpu).expand(B, -1, -1, -1, -1).contiguous()
+    out = aggregation.unprojection(f, p, c)
+    err, _ = _oracle_on_channels(f, p, c, out, [0, 200, 255], b=15)
+    assert err <= TOL
+    mean = aggregation.unprojection(f, p, c, aggregation_method="mean")
+    s = aggregation.unprojection(f, p, c, aggregation_method="sum")
+    assert float((mean - s / V).abs().max()) <= 1e-6
+    # a rank's shard equals the same rows of the whole batch (what the 4-GPU run relies on)
+    part = aggregation.unprojection(f[4:8].contiguous(), p[4:8].contiguous(), c[4:8].contiguous())
+    assert torch.equal(part, out[4:8])
+    del out, mean, s, part
+    torch.cuda.empty_cache()
+
+
+def test_config4_large_volume_64bit_indexing(gpu):
+    """configs[4] geometry: 128^3 grid, 4 views, 512 ch -- one sample's volume is 4.3 GB (> 2^32 bytes), two samples
+    are checked so that every 64-bit offset path (sample, channel, voxel) is exercised by both kernels."""
+    torch.manual_seed(4)
+    B, V, C, H, S = 2, 4, 512, 96, 128
+    _, proj, coords = _ring_problem(B=1, V=V, C=1, H=H, W=H, vol=(S, S, S), seed=4, theta=0.0)
+    f = torch.randn(B, V, C, H, H, device=gpu)
+    p = torch.from_numpy(proj).to(gpu).expand(B, -1, -1, -1).contiguous()
+    c = torch.from_numpy(coords).to(gpu).expand(B, -1, -1, -1, -1).contiguous()
+    out = aggregation.unprojection(f, p, c)                    # brick variant
+    assert out.numel() * 4 >= 2 ** 33 and out[0].numel() * 4 >= 2 ** 32
+    err, _ = _oracle_on_channels(f, p, c, out, [0, 511], b=1)
+    assert err <= TOL
+    gat = aggregation.unprojection(f, p, c, variant="gather")
+    worst = 0.0
+    for ch in (0, 255, 256, 511):                              # compare kernels plane by plane (keeps temporaries small)
+        worst = max(worst, float((out[:, ch] - gat[:, ch]).abs().max()))
+    assert worst <= 2e-6
+    del out, gat
+    torch.cuda.empty_cache()
