@@ -131,12 +131,14 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_slots * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
 
-    // XCD-aware order: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous
-    // range of bricks so that neighbouring windows meet in the same L2.  Placement only affects speed.
-    const int per_xcd = (total_blocks + 7) >> 3;
-    const int work = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (work >= total_blocks) return;
-    const int b = work / bricks_per_sample, brick = work % bricks_per_sample;
+    // XCD-aware order.  Blocks i, i+8, ... share an XCD (round-robin dispatch; placement only affects speed).  All eight
+    // XCDs work on the SAME sample at a time, each on a contiguous eighth of its bricks: neighbouring windows meet in one
+    // L2, and the feature planes live across the chip are one or two samples (37.7 MB each at the north-star size) -- they
+    // stay in the 256 MB Infinity Cache instead of being re-fetched from HBM (8 samples at once did not fit: 7.9 GB read).
+    const int share = (bricks_per_sample + 7) >> 3;                              // bricks of one sample per XCD
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = j / share, brick = xcd * share + j % share;
+    if (brick >= bricks_per_sample || b * bricks_per_sample >= total_blocks) return;
     const int kz = brick % nbz, ky = (brick / nbz) % nby, kx = brick / (nbz * nby);
     const long long N = (long long)X * Y * Z;
     const int HW = H * W, nq = C >> 2;
@@ -359,7 +361,7 @@ hipError_t launch_v(const float4 *featK, const float *proj, const float *coords,
     auto kern = k_fwd_brick<METHOD, VT, kNT>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    const int grid = (total + 7) / 8 * 8;
+    const int grid = ((bps + 7) / 8) * 8 * p.B;                                   // (bricks per XCD per sample) x 8 XCDs x samples
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total);
     return hipGetLastError();
 }
