@@ -74,6 +74,19 @@ __device__ __forceinline__ float bilerp(float v00, float v01, float v10, float v
     return __fmaf_rn(v11, w11, __fmaf_rn(v10, w10, __fmaf_rn(v01, w01, __fmul_rn(v00, w00))));
 }
 
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float vmax3(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // ---------------------------------------------------------------- cross-view aggregate (aggregation.py:71-85)
 // s[0..V) are the per-view samples of one (voxel, channel); returns the aggregated value.
 template <int METHOD, int V>
@@ -90,14 +103,23 @@ __device__ __forceinline__ float aggregate(const float (&s)[V])
         for (int v = 1; v < V; ++v) r = fmaxf(r, s[v]);
         return r;
     } else {
+        // max without the canonicalising v_max x,x hipcc puts in front of fmaxf (the samples are never signalling NaNs
+        // that anything downstream could observe), v_max3 where three operands are at hand
         float m = s[0];
+        if constexpr (V >= 3) {
+            m = vmax3(s[0], s[1], s[2]);
 #pragma unroll
-        for (int v = 1; v < V; ++v) m = fmaxf(m, s[v]);
+            for (int v = 3; v + 1 < V; v += 2) m = vmax3(m, s[v], s[v + 1]);
+            if constexpr ((V - 3) % 2 == 1) m = vmax(m, s[V - 1]);
+        } else if constexpr (V == 2) {
+            m = vmax(s[0], s[1]);
+        }
         // e_v = exp(s_v - m) as exp2((s_v - m) * log2e): one fma + v_exp_f32 per view
         const float nm = -m * 1.4426950408889634f;
-        float den = 0.f, num = 0.f;
+        const float e0 = __builtin_amdgcn_exp2f(fmaf(s[0], 1.4426950408889634f, nm));
+        float den = e0, num = e0 * s[0];
 #pragma unroll
-        for (int v = 0; v < V; ++v) {
+        for (int v = 1; v < V; ++v) {
             const float e = __builtin_amdgcn_exp2f(fmaf(s[v], 1.4426950408889634f, nm));
             den += e;
             num = fmaf(e, s[v], num);

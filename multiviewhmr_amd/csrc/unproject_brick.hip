@@ -64,6 +64,30 @@ __device__ __forceinline__ f32x4 lds_tap(const unsigned char *smem, int addr)
     return f32x4{{t.x, t.y, t.z, t.w}};
 }
 
+// 4 x 4 transpose across an aligned lane quad: on entry lane j holds r[i] = value(channel i, z_j); on exit lane j holds
+// r[i] = value(channel j, z_i) -- 4 consecutive z of ONE channel, i.e. 16 contiguous bytes of the output.
+// Two butterfly stages over DPP quad_perm (lane ^ 1, lane ^ 2): 4 moves + 12 selects, no LDS.
+__device__ __forceinline__ void quad_transpose(float (&r)[4], int lane)
+{
+    const bool b0 = lane & 1, b1 = lane & 2;
+    auto xchg = [](float x, int ctrl) {
+        return __builtin_bit_cast(float, ctrl == 1 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false)
+                                                   : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+    };
+    // stage A (partner = lane ^ 1): even lanes collect channels 0 / 2, odd lanes channels 1 / 3, for z_{j} and z_{j^1}
+    {
+        const float ya = xchg(b0 ? r[0] : r[1], 1), yb = xchg(b0 ? r[2] : r[3], 1);
+        const float a0 = b0 ? ya : r[0], a1 = b0 ? r[1] : ya, a2 = b0 ? yb : r[2], a3 = b0 ? r[3] : yb;
+        r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
+    }
+    // stage B (partner = lane ^ 2): lanes 0,1 keep the first channel of their pair and fetch its z_2, z_3; lanes 2,3 the second
+    {
+        const float ya = xchg(b1 ? r[0] : r[2], 2), yb = xchg(b1 ? r[1] : r[3], 2);
+        const float c0 = b1 ? ya : r[0], c1 = b1 ? yb : r[1], c2 = b1 ? r[2] : ya, c3 = b1 ? r[3] : yb;
+        r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
+    }
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n: wait until at most n vector-memory operations of this wave
 // (loads, LDS-DMA and stores count together, in issue order) are still outstanding
 __device__ __forceinline__ void wait_vmcnt(int n)
@@ -259,62 +283,75 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 if (l_dst[r] >= 0) glds16(src, g_off[r], lds_base + (unsigned)uniform(l_dst[r] + boff));
         };
         // ---- channel-quad loop, software-pipelined inside every wave (ring of nb LDS buffers):
-        //   iteration q, once per view u:
-        //                 issue the 4 ds_read_b128 of view u, quad q+1  (its buffer was completed by the last barrier)
-        //                 cross-view aggregate + stores of quad q       (VALU work that covers the LDS latency)
-        //                 bilinear fma of view u, quad q+1 -> sn        (first use of the reads)
+        //   iteration q:  issue all 4*V ds_read_b128 of quad q+1         (its buffer was completed by the last barrier)
+        //                 cross-view aggregate + store of quad q         (VALU work that covers the LDS latency)
+        //                 bilinear fma of quad q+1 -> s                  (first use of the reads)
         //   then          issue the DMA of quad q+nb                    (into the buffer quad q used)
         //                 retire this wave's DMA of quad q+2, barrier
-        // The barrier orders LDS traffic only; the counted vmcnt leaves younger DMAs and the output stores in flight.
+        // The barrier orders LDS traffic only; the counted vmcnt leaves younger DMAs and the output store in flight.
         // Register budget (128 VGPRs at 16 waves/CU, and NO spills: a scratch access is a vector-memory operation and
         // would break the counted vmcnt waits below -- the Makefile fails the build if this kernel uses scratch):
         // one view's taps (4 x b128) are in flight at a time; sub-step u reads view u of quad q+1, aggregates and
         // stores its share of quad q's channels meanwhile, then folds the taps into the next quad's samples.
-        f32x4 T[4];
-        float sA[4][VT], sB[4][VT];                                              // samples of the quad being reduced / being built
-        auto read_view = [&](int q, int v) {
-            const int base = a0[v] + ring(q), row1 = base + ws16[v];
-            T[0] = lds_tap(smem, base); T[1] = lds_tap(smem, base + 16);
-            T[2] = lds_tap(smem, row1); T[3] = lds_tap(smem, row1 + 16);
-        };
-        auto bilerp_view = [&](float (&sn)[4][VT], int v) {
+        f32x4 T[VT][4];                                                          // all taps of quad q+1, in flight
+        float s[4][VT];                                                          // samples of quad q
+        auto read_all = [&](int q) {
+            const int boff = ring(q);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) sn[i][v] = bilerp(T[0].v[i], T[1].v[i], T[2].v[i], T[3].v[i], w00[v], w01[v], w10[v], w11[v]);
+            for (int v = 0; v < VT; ++v) {
+                const int base = a0[v] + boff, row1 = base + ws16[v];
+                T[v][0] = lds_tap(smem, base); T[v][1] = lds_tap(smem, base + 16);
+                T[v][2] = lds_tap(smem, row1); T[v][3] = lds_tap(smem, row1 + 16);
+            }
         };
-        // stores go through a buffer descriptor rebuilt per quad from wave-uniform values: base = this sample's quad q,
-        // scalar offset = channel * N * 4, lane offset = voxel * 4 -- no per-lane 64-bit address arithmetic
+        auto bilerp_all = [&]() {
+#pragma unroll
+            for (int v = 0; v < VT; ++v)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i][v] = bilerp(T[v][0].v[i], T[v][1].v[i], T[v][2].v[i], T[v][3].v[i], w00[v], w01[v], w10[v], w11[v]);
+        };
+        // Stores: one buffer_store_dwordx4 per wave per quad.  A lane quad (4 consecutive z of one column) transposes its
+        // 4 channels x 4 voxels in registers, so lane j writes channel j's 16 contiguous bytes; 8 quads of a column make a
+        // 128-B run per channel.  (Four dword stores per quad stalled the waves at vector-memory issue: the measured 37 %.)
+        // Descriptor rebuilt per quad from wave-uniform values: base = this sample's quad q; per-lane byte offset =
+        // channel (lane & 3) * N * 4 + first voxel of the lane quad * 4.
         const unsigned chan_bytes = (unsigned)(N * 4);
-        auto reduce_store = [&](const float (&sc)[4][VT], __amdgpu_buffer_rsrc_t rs, int c) {
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, aggregate<METHOD, VT>(sc[c])), rs, (int)voxb, (int)(c * chan_bytes), 0);
+        const unsigned vox_quad = (unsigned)__builtin_amdgcn_update_dpp(0, (int)voxb, 0x00, 0xF, 0xF, false);   // lane 0 of the quad
+        const unsigned st_off = vox_quad + (unsigned)(lane & 3) * chan_bytes;
+        float res[4];
+        auto store_quad = [&](__amdgpu_buffer_rsrc_t rs) {
+            quad_transpose(res, lane);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
+                             __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
+            __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, 0);
         };
-        // one quad: reduce + store quad q from sc while the taps of quad q+1 are read and folded into sn
-        auto quad_step = [&](int q, const float (&sc)[4][VT], float (&sn)[4][VT]) {
+        // one quad: all 4 * VT taps of quad q+1 go in flight, quad q is aggregated and stored under them, then the taps
+        // are folded into the samples of quad q+1 (the old samples are dead by then: one sample array suffices)
+        auto quad_step = [&](int q) {
             const bool more = q + 1 < nq;
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
+            if (more) read_all(q + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int u = 0; u < VT; ++u) {
-                if (more) read_view(q + 1, u);
-#pragma unroll
-                for (int c = (4 * u) / VT; c < (4 * (u + 1)) / VT; ++c) reduce_store(sc, rs, c);
-                if (more) bilerp_view(sn, u);
-            }
+            for (int c = 0; c < 4; ++c) res[c] = aggregate<METHOD, VT>(s[c]);
+            store_quad(rs);
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) bilerp_all();
             const bool issue = q + nb < nq;
             if (issue) dma(q + nb);
-            if (q + 2 < nq) wait_vmcnt(nb == 3 ? 4 + (issue ? n_c : 0) : 0);
+            if (q + 2 < nq) wait_vmcnt(nb == 3 ? 1 + (issue ? n_c : 0) : 0);
             lds_barrier();
         };
 
         for (int q = 0; q < nb && q < nq; ++q) dma(q);
         wait_vmcnt(nb == 3 && nq > 2 ? n_c : 0);                                 // quads 0 and 1 have landed
         lds_barrier();
-#pragma unroll
-        for (int v = 0; v < VT; ++v) { read_view(0, v); bilerp_view(sA, v); }
+        read_all(0);
+        bilerp_all();
         lds_barrier();                       // every wave is done with quad 0's buffer before anyone's DMA reuses it
 #pragma nounroll
-        for (int q = 0; q < nq; q += 2) {                                        // ping-pong: no copies between the two sample sets
-            quad_step(q, sA, sB);
-            if (q + 1 < nq) quad_step(q + 1, sB, sA);
-        }
+        for (int q = 0; q < nq; ++q) quad_step(q);
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (clamped taps, zero weights outside)
         int o00[VT], o01[VT], o10[VT], o11[VT];
