@@ -6,10 +6,27 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <unordered_map>
+
 #include "device_common.h"
 #include "kernels.h"
 
 using namespace mvhmr;
+
+namespace mvhmr {
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes)
+{
+    static std::mutex mu;
+    static std::unordered_map<const void *, size_t> granted;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = granted.find(kernel);
+    if (it != granted.end() && it->second >= bytes) return hipSuccess;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) granted[kernel] = bytes;
+    return e;
+}
+}  // namespace mvhmr
 
 namespace {
 

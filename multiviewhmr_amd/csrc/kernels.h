@@ -15,6 +15,11 @@ struct Problem {
     int feat_f16, out_f16;    // storage types
 };
 
+// Raises a kernel's dynamic-LDS limit once (per kernel, per process, remembering the largest size asked for): the
+// attribute call is not a stream operation, so it is kept off the per-launch path and out of graph captures after
+// the first (warm-up) launch.
+hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);
+
 // (B*V, C, HW) -> (B*V, HW, C4), zero-padding channels C..C4; and the inverse for gradients
 // (fp32 channels-last accumulator -> feature dtype, planar).
 hipError_t launch_to_channels_last(const void *src, void *dst, const Problem &p, hipStream_t s);

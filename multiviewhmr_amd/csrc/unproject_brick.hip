@@ -396,7 +396,7 @@ hipError_t launch_v(const float4 *featK, const float *proj, const float *coords,
     const int slots = pick_lds_slots();
     const size_t lds = (size_t)slots * 16 + sizeof(BrickShared<VT>);
     auto kern = k_fwd_brick<METHOD, VT, kNT>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const int grid = ((bps + 7) / 8) * 8 * p.B;                                   // (bricks per XCD per sample) x 8 XCDs x samples
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total);

@@ -329,7 +329,7 @@ static hipError_t fwd_dispatch_v(const TF *featT, const float *proj, const float
     const size_t lds = sizeof(TapRec) * kTileVox * (size_t)p.V + sizeof(f32x4) * kTileVox * (size_t)tstride;
     const dim3 grid((unsigned)((p.N + kTileVox - 1) / kTileVox), (unsigned)p.B, (unsigned)((Q + kGroupQuads - 1) / kGroupQuads));
     auto go = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, featT, proj, coords, out, p.V, p.C, p.C4, p.H, p.W, p.N, tstride);
         return hipGetLastError();
@@ -371,7 +371,7 @@ static hipError_t bwd_dispatch_v(const TO *go_, const TF *featT, const float *pr
     const size_t lds = sizeof(TapRec) * kTileVox * (size_t)p.V + sizeof(float) * kGroupCh * 65;
     const dim3 grid((unsigned)((p.N + kTileVox - 1) / kTileVox), (unsigned)p.B, (unsigned)((p.C + kGroupCh - 1) / kGroupCh));
     auto go = [&](auto kern) -> hipError_t {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, go_, featT, proj, coords, gradT, p.V, p.C, p.C4, p.H, p.W, p.N);
         return hipGetLastError();

@@ -397,3 +397,34 @@ def test_config4_large_volume_64bit_indexing(gpu):
     assert worst <= 2e-6
     del out, gat
     torch.cuda.empty_cache()
+
+
+def test_forward_is_graph_capturable(gpu):
+    """The C ABI promises no allocation / no host sync inside a call: capture the two calls of a step into a HIP graph
+    (after one eager warm-up) and replay it on new input values."""
+    feats, proj, coords = _ring_problem(B=2, V=4, C=16, H=32, W=32, vol=(4, 8, 32), seed=21)
+    f, p, c = torch.from_numpy(feats).to(gpu), torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    L = _capi.lib()
+    desc = aggregation._make_desc(f, c, _capi.AGG["softmax"], torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["auto"])
+    need = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc))
+    ws = torch.empty(max(need, 1), dtype=torch.uint8, device=gpu)
+    out = torch.empty(2, 16, 4, 8, 32, device=gpu)
+    vp = ctypes.c_void_p
+
+    def call(stream):
+        _capi.check(L.mvhmr_unproject_forward(ctypes.byref(desc), vp(f.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(out.data_ptr()),
+                                              vp(ws.data_ptr()), need, vp(stream.cuda_stream)))
+
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        call(side)                                   # warm-up outside the capture (one-time kernel attribute set-up)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        call(torch.cuda.current_stream())
+    f.copy_(torch.randn_like(f))                     # new values, same buffers
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    ref = cport.forward(f.cpu().numpy(), proj, coords, "softmax")
+    assert float(np.abs(out.cpu().numpy() - ref).max()) <= TOL
