@@ -99,6 +99,14 @@ int variant_conflict(const mvhmr_unproject_desc *d, const Problem &p, int varian
 // the gradient can be accumulated straight into grad_features when that already is fp32 channels-last
 bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->feat_layout == MVHMR_LAYOUT_BVHWC && !p.feat_f16; }
 
+// The brick backward (LDS-privatised accumulation) only runs when asked for explicitly: measured 189 ms against 104 ms
+// for the gather backward at the north-star size -- ds_add_f32 costs ~116 cycles per wave instruction on gfx950 and the
+// kernel issues 64 of them per voxel and channel quad (profiles/r01_bwd_brick_pmc.txt).  AUTO keeps the gather backward.
+bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
+{
+    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant == MVHMR_VARIANT_BRICK && brick_supported(p);
+}
+
 int check_ws(void *ws, size_t have, size_t need)
 {
     if (need == 0) return MVHMR_OK;
@@ -155,6 +163,7 @@ size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
+    if (bwd_uses_brick(desc, p)) return featT_bytes(p) + gradT_bytes(p);
     size_t need = desc->feat_layout == MVHMR_LAYOUT_BVCHW ? featT_bytes(p) : 0;
     if (!grad_in_place(desc, p)) need += gradT_bytes(p);
     return need;
@@ -207,6 +216,18 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
     if (rc != MVHMR_OK) return rc;
 
     unsigned char *ws = static_cast<unsigned char *>(workspace);
+    if (desc->variant == MVHMR_VARIANT_BRICK && !bwd_uses_brick(desc, p))
+        return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype / layout");
+    if (bwd_uses_brick(desc, p)) {
+        float *gradK = reinterpret_cast<float *>(ws + featT_bytes(p));
+        rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
+        if (rc != MVHMR_OK) return rc;
+        hipError_t e = hipMemsetAsync(gradK, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
+        if (e != hipSuccess) return launched(e, "gradient clear");
+        rc = launched(launch_bwd_brick(ws, grad_out, proj, coords, gradK, p, s), "brick backward");
+        if (rc != MVHMR_OK) return rc;
+        return launched(launch_quad_grad_to_planar(gradK, grad_features, p, s), "gradient layout pass");
+    }
     const void *featT = features;
     if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) {
         rc = launched(launch_to_channels_last(features, ws, p, s), "layout pass");

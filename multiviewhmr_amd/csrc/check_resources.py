@@ -5,7 +5,7 @@ Reads hipcc's -Rpass-analysis=kernel-resource-usage output."""
 import re
 import sys
 
-NO_SCRATCH = ("k_fwd_brick",)          # name fragments of the kernels under the rule
+NO_SCRATCH = ("k_fwd_brick",)          # kernels with hand-counted vmcnt waits (k_bwd_brick only uses vmcnt(0))
 EXEMPT = re.compile(r"^$")
 text = open(sys.argv[1]).read()
 bad = []

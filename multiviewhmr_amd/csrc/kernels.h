@@ -40,6 +40,11 @@ hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, h
 hipError_t launch_fwd_brick(const void *featK, const float *proj, const float *coords, void *out, const Problem &p,
                             hipStream_t s);
 
+// brick backward: featK quad-planar features, gradK zeroed fp32 quad-planar accumulator (same shape)
+hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK,
+                            const Problem &p, hipStream_t s);
+hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Problem &p, hipStream_t s);
+
 hipError_t launch_build_coords(float *coords, const float *rot, const float *center, int B, int S,
                                const double pos[3], const double sides[3], hipStream_t s);
 

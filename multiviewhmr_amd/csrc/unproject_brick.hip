@@ -26,109 +26,10 @@
 //   zero padding = a tap outside the image has weight 0 (make_taps) and its staged pixel is clamped into
 //            the image, i.e. contributes 0 * finite (aggregation.py:55-58, padding_mode='zeros').
 // The cross-view aggregate runs in registers exactly as in the gather variant (aggregation.py:71-85).
-#include "device_common.h"
+#include "brick_common.h"
 #include "kernels.h"
 
 namespace mvhmr {
-
-constexpr int kBZ = 32;            // z extent of a brick: 128-B output runs
-constexpr int kBX = 4;
-constexpr int kMaxChunks = 5;      // 64-slot DMA chunks per wave per quad
-constexpr int kZeroSlots = 128;    // always-zero 16-B slots at the head of every ring buffer (row stride <= 126)
-constexpr int kZeroBytes = kZeroSlots * 16;
-
-// workgroup barrier that waits for this wave's LDS operations only (not for global loads / stores in flight)
-__device__ __forceinline__ void lds_barrier()
-{
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-
-// LDS-DMA of 16 B per lane: lane l's bytes land at lds_dst + 16*l (lds_dst wave-uniform), read from base + voff[l].
-// Written as inline asm on purpose: hipcc tracks the builtin form as a pending LDS write and puts s_waitcnt vmcnt(0)
-// in front of every later ds_read, which drains the whole ring and the output stores each quad.  The asm form is
-// outside its bookkeeping; completion is counted by hand (wait_vmcnt) before the barrier that precedes the reads.
-__device__ __forceinline__ void glds16(const void *base, unsigned voff, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(voff), "s"(base), "s"(lds_dst)
-                 : "memory");
-}
-
-__device__ __forceinline__ f32x4 lds_tap(const unsigned char *smem, int addr)
-{
-    const float4 t = *reinterpret_cast<const float4 *>(smem + addr);
-    return f32x4{{t.x, t.y, t.z, t.w}};
-}
-
-// 4 x 4 transpose across an aligned lane quad: on entry lane j holds r[i] = value(channel i, z_j); on exit lane j holds
-// r[i] = value(channel j, z_i) -- 4 consecutive z of ONE channel, i.e. 16 contiguous bytes of the output.
-// Two butterfly stages over DPP quad_perm (lane ^ 1, lane ^ 2): 4 moves + 12 selects, no LDS.
-__device__ __forceinline__ void quad_transpose(float (&r)[4], int lane)
-{
-    const bool b0 = lane & 1, b1 = lane & 2;
-    auto xchg = [](float x, int ctrl) {
-        return __builtin_bit_cast(float, ctrl == 1 ? __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false)
-                                                   : __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
-    };
-    // stage A (partner = lane ^ 1): even lanes collect channels 0 / 2, odd lanes channels 1 / 3, for z_{j} and z_{j^1}
-    {
-        const float ya = xchg(b0 ? r[0] : r[1], 1), yb = xchg(b0 ? r[2] : r[3], 1);
-        const float a0 = b0 ? ya : r[0], a1 = b0 ? r[1] : ya, a2 = b0 ? yb : r[2], a3 = b0 ? r[3] : yb;
-        r[0] = a0; r[1] = a1; r[2] = a2; r[3] = a3;
-    }
-    // stage B (partner = lane ^ 2): lanes 0,1 keep the first channel of their pair and fetch its z_2, z_3; lanes 2,3 the second
-    {
-        const float ya = xchg(b1 ? r[0] : r[2], 2), yb = xchg(b1 ? r[1] : r[3], 2);
-        const float c0 = b1 ? ya : r[0], c1 = b1 ? yb : r[1], c2 = b1 ? r[2] : ya, c3 = b1 ? r[3] : yb;
-        r[0] = c0; r[1] = c1; r[2] = c2; r[3] = c3;
-    }
-}
-
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n: wait until at most n vector-memory operations of this wave
-// (loads, LDS-DMA and stores count together, in issue order) are still outstanding
-__device__ __forceinline__ void wait_vmcnt(int n)
-{
-    switch (uniform(n)) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-
-template <int VT>
-struct BrickShared {
-    int bbox[VT][4];               // xmin, ymin, xmax, ymax of the nw taps (valid voxels only)
-    float proj[VT][12];
-};
-
-__device__ __forceinline__ int wave_min(int x)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const int y = __shfl_xor(x, m); x = y < x ? y : x; }
-    return x;
-}
-__device__ __forceinline__ int wave_max(int x)
-{
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const int y = __shfl_xor(x, m); x = y > x ? y : x; }
-    return x;
-}
 
 // features (BV, C, HW) fp32 -> (BV, C/4, HW, 4)
 __global__ void __launch_bounds__(256)

@@ -1,0 +1,326 @@
+// "brick" variant of the backward pass (gradient w.r.t. the feature maps).  EXPERIMENTAL: correct (parity-tested) but
+// slower than the gather backward on gfx950 -- LDS float atomics run at ~116 cycles per wave instruction, so the
+// ds_add_f32 accumulation below saturates the LDS pipe (189 ms vs 104 ms at the north-star size).  Selected only by
+// variant = brick; kept as the starting point for a non-atomic (turn-taking read-add-write) accumulation.
+//
+// The gather backward scatters every tap with a global float atomic: 4 taps x 4 B per (voxel, view, channel) = 137 GB of
+// atomic traffic at the north-star size against a chip-wide rate of ~1.3 TB/s -- ~0.1 s.  Here the same bricks and
+// windows as the forward (unproject_brick.hip) are used to privatise the accumulation:
+//   per brick and channel quad   re-sample the brick's voxels from the LDS-staged feature window (recompute, nothing
+//                                is saved by the forward), apply the aggregate's Jacobian (aggregate_grad), and add
+//                                ds * w into a GRADIENT window in LDS with ds_add_f32 (planar per channel, so that a
+//                                wave's lanes -- different window rows -- spread over the banks);
+//   then                         flush the gradient window: one global float atomic per window pixel and channel, issued
+//                                as 16 pixels x 4 channels = 256 contiguous bytes of the quad-planar accumulator per wave
+//                                instruction (the full-rate shape on gfx950) -- ~20 GB instead of 137 GB.
+// The accumulator is fp32 quad-planar (B,V,C/4,Hf,Wf,4), zeroed by the caller; a layout pass turns it into the caller's
+// gradient tensor.  Float atomics: run-to-run differences in the last bits (documented in the ABI).
+// Autograd semantics as in the gather variant / the oracle: zero-weight taps (outside the image, z <= 0) receive nothing.
+#include "brick_common.h"
+#include "kernels.h"
+
+namespace mvhmr {
+
+// LDS: [ feature buffer 0 | feature buffer 1 | 4 gradient planes | BrickShared ]
+//   feature buffer = kZeroBytes of zeros + cap 16-B slots (as in the forward)
+//   gradient plane = (kZeroSlots + cap) floats; the first kZeroSlots only ever receive +0 (samples that are identically zero)
+constexpr int kBwdLdsBytes = 160 * 1024 - 1024;
+
+template <int METHOD, int VT, int NT>
+__global__ void __launch_bounds__(NT)
+k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out, const float *__restrict__ proj,
+            const float *__restrict__ coords, float *__restrict__ gradK, int C, int H, int W, int X, int Y, int Z, int nby,
+            int nbz, int bricks_per_sample, int lds_bytes, int total_blocks)
+{
+    constexpr int BY = NT / 128, NW = NT / 64;
+    extern __shared__ __align__(16) unsigned char smem[];
+    BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_bytes);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
+
+    const int share = (bricks_per_sample + 7) >> 3;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = j / share, brick = xcd * share + j % share;
+    if (brick >= bricks_per_sample || b * bricks_per_sample >= total_blocks) return;
+    const int kz = brick % nbz, ky = (brick / nbz) % nby, kx = brick / (nbz * nby);
+    const long long N = (long long)X * Y * Z;
+    const int HW = H * W, nq = C >> 2;
+
+    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = proj[((long long)b * VT) * 12 + tid];
+    if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
+    __syncthreads();
+
+    // ---- this lane's voxel and its tap records (identical to the forward)
+    const int col = wave * 2 + (lane >> 5);
+    const int l5 = lane & 31;
+    const int zin = l5 < 4 ? l5 : l5 < 12 ? 12 + l5 : l5 < 16 ? l5 - 8 : l5 < 20 ? 8 + l5 : l5 < 28 ? l5 - 12 : l5;
+    const int vx = kx * kBX + (col & 3), vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
+    const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);
+    float w00[VT], w01[VT], w10[VT], w11[VT];
+    int tx[VT], ty[VT];
+    unsigned valid = 0;
+    {
+        const float *Xp = coords + ((long long)b * N + vox) * 3;
+        const float c0 = Xp[0], c1 = Xp[1], c2 = Xp[2];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
+            w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
+            tx[v] = t.rx0; ty[v] = t.ry0;
+            if (t.any) valid |= 1u << v;
+            const int big = 1 << 30;
+            const int xmin = wave_min(t.any ? t.rx0 : big), ymin = wave_min(t.any ? t.ry0 : big);
+            const int xmax = wave_max(t.any ? t.rx0 : -big), ymax = wave_max(t.any ? t.ry0 : -big);
+            if (lane == 0 && xmax >= xmin) {
+                atomicMin(&sh->bbox[v][0], xmin); atomicMin(&sh->bbox[v][1], ymin);
+                atomicMax(&sh->bbox[v][2], xmax); atomicMax(&sh->bbox[v][3], ymax);
+            }
+        }
+    }
+    __syncthreads();
+
+    int wx0[VT], wy0[VT], ws[VT], bwv[VT], bhv[VT], nch[VT + 1], slot0[VT];
+    nch[0] = 0;
+    int used = 0, max_stride = 0;
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        const int xmin = uniform(sh->bbox[v][0]), ymin = uniform(sh->bbox[v][1]);
+        const int xmax = uniform(sh->bbox[v][2]), ymax = uniform(sh->bbox[v][3]);
+        int bw = 0, bh = 0;
+        if (xmax >= xmin) { bw = xmax - xmin + 2; bh = ymax - ymin + 2; }
+        const int stride = bw | 1;
+        const int chunks = (stride * bh + 63) >> 6;
+        wx0[v] = xmin; wy0[v] = ymin; ws[v] = stride; bwv[v] = bw; bhv[v] = bh;
+        max_stride = stride > max_stride ? stride : max_stride;
+        slot0[v] = used;
+        used += chunks << 6;
+        nch[v + 1] = nch[v] + chunks;
+    }
+    // capacity: 2 * (kZeroBytes + 16 cap) + 4 * 4 * (kZeroSlots + cap) <= kLdsBytes.  Compile-time, so that the plane and
+    // buffer strides fold into the immediate offsets of the ds_ instructions (run-time strides cost 32 address registers)
+    constexpr int cap = ((kBwdLdsBytes - 2 * kZeroBytes - 16 * kZeroSlots) / 48) & ~63;
+    constexpr int buf_bytes = kZeroBytes + cap * 16;
+    constexpr int plane_floats = kZeroSlots + cap;
+    float *const gplanes = reinterpret_cast<float *>(smem + 2 * buf_bytes);
+    const bool fits = used <= cap && nch[VT] <= kMaxChunks * NW && max_stride + 2 <= kZeroSlots;
+    const float4 *const fk = featK + (long long)b * VT * nq * HW;
+    float *const gk = gradK + (long long)b * VT * nq * HW * 4;
+    const float *const gobase = grad_out + (long long)b * C * N;
+    const unsigned chan_bytes = (unsigned)(N * 4);
+    const unsigned voxb = vox * 4u;
+
+    if (fits) {
+        for (int i = tid; i < kZeroSlots * 2; i += NT)
+            *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < 4 * plane_floats; i += NT) gplanes[i] = 0.f;
+
+        int a0[VT], ws16[VT], ga[VT];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const bool ok = (valid >> v) & 1u;
+            const int s0 = slot0[v] + (ty[v] - wy0[v]) * ws[v] + (tx[v] - wx0[v]);
+            a0[v] = ok ? kZeroBytes + s0 * 16 : 0;
+            ga[v] = ok ? kZeroSlots + s0 : 0;                                     // float index inside a gradient plane
+            ws16[v] = ws[v] * 16;
+        }
+        // ---- chunks of this wave (64 consecutive window slots of one view): DMA source + flush destination
+        unsigned g_off[kMaxChunks];                                              // bit 0: the lane's slot is a real window pixel inside the image
+        int l_dst[kMaxChunks], c_slot[kMaxChunks];
+#pragma unroll
+        for (int r = 0; r < kMaxChunks; ++r) {
+            const int c = wave + r * NW;
+            l_dst[r] = -1; c_slot[r] = 0; g_off[r] = 0;
+            if (c < nch[VT]) {
+                int v = 0;
+#pragma unroll
+                for (int u = 1; u < VT; ++u) v += c >= nch[u] ? 1 : 0;
+                int sv = ws[0], ox = wx0[0], oy = wy0[0], c0 = nch[0], s0 = slot0[0], bw = bwv[0], bh = bhv[0];
+#pragma unroll
+                for (int u = 1; u < VT; ++u) if (v == u) { sv = ws[u]; ox = wx0[u]; oy = wy0[u]; c0 = nch[u]; s0 = slot0[u]; bw = bwv[u]; bh = bhv[u]; }
+                const int jj = c - c0, slot = (jj << 6) + lane;
+                const int py = slot / sv, px = slot - py * sv;
+                const int gx = ox + px, gy = oy + py;
+                const unsigned live = (px < bw && py < bh && gx >= 0 && gx < W && gy >= 0 && gy < H) ? 1u : 0u;
+                const int cx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx), cy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+                g_off[r] = ((unsigned)((v * nq) * HW + cy * W + cx) * 16u) | live;
+                l_dst[r] = kZeroBytes + (s0 + (jj << 6)) * 16;
+                c_slot[r] = kZeroSlots + s0 + (jj << 6);
+            }
+        }
+        const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
+        auto dma = [&](int q) {
+            const float4 *src = fk + (long long)q * HW;
+            const int boff = (q & 1) * buf_bytes;
+#pragma unroll
+            for (int r = 0; r < kMaxChunks; ++r)
+                if (l_dst[r] >= 0) glds16(src, g_off[r] & ~15u, lds_base + (unsigned)uniform(l_dst[r] + boff));
+        };
+
+        dma(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_barrier();
+#pragma nounroll
+        for (int q = 0; q < nq; ++q) {
+            if (q + 1 < nq) dma(q + 1);
+            // grad_out of this voxel's 4 channels (128-B runs per channel across the wave)
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gobase) + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
+            float g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)voxb, (int)(i * chan_bytes), 0));
+            // re-sample
+            const int boff = (q & 1) * buf_bytes;
+            float s[4][VT];
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {                                       // one view at a time: 16 tap registers, not 64
+                __builtin_amdgcn_sched_barrier(0);
+                const int base = a0[v] + boff, row1 = base + ws16[v];
+                const f32x4 ta = lds_tap(smem, base), tb = lds_tap(smem, base + 16), tc = lds_tap(smem, row1), td = lds_tap(smem, row1 + 16);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i][v] = bilerp(ta.v[i], tb.v[i], tc.v[i], td.v[i], w00[v], w01[v], w10[v], w11[v]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // Jacobian of the aggregate, then scatter into the LDS gradient window
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {                                        // one channel at a time (fenced: registers)
+                __builtin_amdgcn_sched_barrier(0);
+                float ds[VT];
+                aggregate_grad<METHOD, VT>(s[i], g[i], ds);
+                float *pl = gplanes + i * plane_floats;
+#pragma unroll
+                for (int v = 0; v < VT; ++v) {
+                    float *p = pl + ga[v];
+                    atomicAdd(p, ds[v] * w00[v]);
+                    atomicAdd(p + 1, ds[v] * w01[v]);
+                    atomicAdd(p + ws[v], ds[v] * w10[v]);
+                    atomicAdd(p + ws[v] + 1, ds[v] * w11[v]);
+                }
+            }
+            lds_barrier();                                                       // every add of this quad has landed in LDS
+            // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction
+            float *gq = gk + (long long)q * HW * 4;
+#pragma unroll
+            for (int r = 0; r < kMaxChunks; ++r) {
+                if (l_dst[r] < 0) continue;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int srcl = 16 * jj + (lane >> 2), ch = lane & 3;
+                    const unsigned off = (unsigned)__shfl((int)g_off[r], srcl);    // byte offset of that slot's pixel (view base included) | live
+                    const unsigned lv = off & 1u;
+                    float *pl = gplanes + ch * plane_floats + c_slot[r] + srcl;
+                    const float val = *pl;
+                    *pl = 0.f;                                                    // ready for the next quad
+                    if (lv && val != 0.f) atomicAdd(gq + (off >> 2) + ch, val);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the next quad's feature window has landed
+            lds_barrier();
+        }
+    } else {
+        // ---- windows do not fit: scatter straight to the accumulator (global atomics per tap)
+        int o00[VT], o01[VT], o10[VT], o11[VT];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const int x0 = tx[v] < 0 ? 0 : tx[v], y0 = ty[v] < 0 ? 0 : ty[v];
+            const int x1 = tx[v] + 1 > W - 1 ? W - 1 : tx[v] + 1, y1 = ty[v] + 1 > H - 1 ? H - 1 : ty[v] + 1;
+            const int base = (v * nq) * HW;
+            o00[v] = base + y0 * W + x0; o01[v] = base + y0 * W + x1; o10[v] = base + y1 * W + x0; o11[v] = base + y1 * W + x1;
+        }
+        for (int q = 0; q < nq; ++q) {
+            const float4 *src = fk + (long long)q * HW;
+            float *gq = gk + (long long)q * HW * 4;
+            float s[4][VT];
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                const float4 a = src[o00[v]], bb = src[o01[v]], c = src[o10[v]], d = src[o11[v]];
+                s[0][v] = bilerp(a.x, bb.x, c.x, d.x, w00[v], w01[v], w10[v], w11[v]);
+                s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[v], w01[v], w10[v], w11[v]);
+                s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]);
+                s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float g = gobase[(long long)(q * 4 + i) * N + vox];
+                float ds[VT];
+                aggregate_grad<METHOD, VT>(s[i], g, ds);
+#pragma unroll
+                for (int v = 0; v < VT; ++v) {
+                    if (w00[v] != 0.f) atomicAdd(gq + (long long)o00[v] * 4 + i, ds[v] * w00[v]);
+                    if (w01[v] != 0.f) atomicAdd(gq + (long long)o01[v] * 4 + i, ds[v] * w01[v]);
+                    if (w10[v] != 0.f) atomicAdd(gq + (long long)o10[v] * 4 + i, ds[v] * w10[v]);
+                    if (w11[v] != 0.f) atomicAdd(gq + (long long)o11[v] * 4 + i, ds[v] * w11[v]);
+                }
+            }
+        }
+    }
+}
+
+// fp32 quad-planar accumulator (BV, C/4, HW, 4) -> planar gradient (BV, C, HW)
+__global__ void __launch_bounds__(256)
+k_quad_planar_to_planar(const float4 *__restrict__ src, float *__restrict__ dst, int C, int HW)
+{
+    const long long bv = blockIdx.z;
+    const int q = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const float4 g = src[(bv * (C >> 2) + q) * HW + p];
+    float *d = dst + (bv * C + q * 4) * HW + p;
+    d[0] = g.x; d[HW] = g.y; d[2 * (long long)HW] = g.z; d[3 * (long long)HW] = g.w;
+}
+
+namespace {
+constexpr int kNTb = 1024;
+constexpr int kBYb = kNTb / 128;
+
+template <int METHOD, int VT>
+hipError_t launch_bv(const float4 *featK, const float *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
+                     hipStream_t s)
+{
+    const int nbx = p.X / kBX, nby = p.Y / kBYb, nbz = p.Z / kBZ;
+    const int bps = nbx * nby * nbz, total = bps * p.B;
+    const int lds_bytes = kBwdLdsBytes;
+    const size_t lds = (size_t)lds_bytes + sizeof(BrickShared<VT>);
+    auto kern = k_bwd_brick<METHOD, VT, kNTb>;
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    const int grid = ((bps + 7) / 8) * 8 * p.B;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNTb), lds, s, featK, grad_out, proj, coords, gradK, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps,
+                       lds_bytes, total);
+    return hipGetLastError();
+}
+
+template <int METHOD>
+hipError_t launch_bm(const float4 *featK, const float *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
+                     hipStream_t s)
+{
+    switch (p.V) {
+    case 2: return launch_bv<METHOD, 2>(featK, grad_out, proj, coords, gradK, p, s);
+    case 4: return launch_bv<METHOD, 4>(featK, grad_out, proj, coords, gradK, p, s);
+    }
+    return hipErrorNotSupported;
+}
+}  // namespace
+
+// featK: quad-planar features; gradK: zeroed fp32 quad-planar accumulator of the same shape
+hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
+                            hipStream_t s)
+{
+    if (!brick_supported(p)) return hipErrorNotSupported;
+    const float4 *fk = static_cast<const float4 *>(featK);
+    const float *go = static_cast<const float *>(grad_out);
+    switch (p.method) {
+    case AGG_SOFTMAX: return launch_bm<AGG_SOFTMAX>(fk, go, proj, coords, gradK, p, s);
+    case AGG_SUM: return launch_bm<AGG_SUM>(fk, go, proj, coords, gradK, p, s);
+    case AGG_MEAN: return launch_bm<AGG_MEAN>(fk, go, proj, coords, gradK, p, s);
+    case AGG_MAX: return launch_bm<AGG_MAX>(fk, go, proj, coords, gradK, p, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Problem &p, hipStream_t s)
+{
+    if (p.feat_f16 || p.C % 4) return hipErrorNotSupported;
+    const int HW = p.H * p.W;
+    hipLaunchKernelGGL(k_quad_planar_to_planar, dim3((HW + 255) / 256, p.C / 4, p.B * p.V), dim3(256), 0, s, (const float4 *)gradK, (float *)dst, p.C, HW);
+    return hipGetLastError();
+}
+
+}  // namespace mvhmr

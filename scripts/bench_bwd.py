@@ -1,7 +1,7 @@
 """Times forward+backward through the autograd.Function at a given size (default: BASELINE configs[2] shape, fp32)."""
 import argparse, sys, time
 import numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from multiviewhmr_amd import aggregation
 ap = argparse.ArgumentParser()

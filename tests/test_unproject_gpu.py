@@ -146,6 +146,19 @@ def test_brick_variant_vs_oracle(shape, mode, gpu):
     assert float((out - gat).abs().max()) <= 2e-6         # same arithmetic, two kernels
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_brick_backward_vs_oracle(mode, gpu):
+    """the (experimental) LDS-privatised backward, reachable with variant='brick'"""
+    feats, proj, coords = _ring_problem(B=2, V=4, C=8, H=48, W=48, vol=(8, 8, 32), seed=31)
+    f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick")
+    go = np.random.default_rng(6).standard_normal(tuple(out.shape), dtype=np.float32)
+    out.backward(torch.from_numpy(go).to(gpu))
+    gref = cport.backward(go, feats, proj, coords, mode)
+    assert float(np.abs(f.grad.cpu().numpy() - gref).max()) <= TOL * max(1.0, float(np.abs(gref).max()) / 8.0)
+
+
 def test_brick_variant_with_cameras_inside_the_volume(gpu):
     """adversarial geometry for the window logic: behind-camera voxels, bricks with no valid voxel for a view"""
     d = load_golden("unproj", "adversarial_v4c6")
