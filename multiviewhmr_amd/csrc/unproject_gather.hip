@@ -1,13 +1,13 @@
 // "gather" variant of the fused un-projection: the shape-agnostic kernel pair.
 //
 // Mapping (CDNA4, wave64):
-//   block   = 64 consecutive voxels x one group of up to 256 channels of one sample (256 threads, 4 waves)
+//   block   = 32 consecutive voxels x one group of up to 256 channels of one sample (256 threads, 4 waves)
 //   phase 1 = one thread per (voxel, view): project, build the 4 bilinear taps -> 32-byte record in LDS
 //             (done once, reused by every channel: models/aggregation.py:38-54 hoisted out of the channel dim)
 //   phase 2 = one wave per voxel, one LANE per 4 consecutive channels: the tap records are wave-uniform
 //             (SGPRs), each tap is ONE coalesced 1-KiB read of a channels-last feature row, the
 //             cross-view aggregate runs in registers (no (V,C,N) intermediate, aggregation.py:32,68,78-83)
-//   phase 3 = the (voxel x channel) tile is turned through LDS so every store is a full 256-B row of
+//   phase 3 = the (voxel x channel) tile is turned through LDS so every store writes 128-B runs of
 //             consecutive voxels of one channel of the (B,C,X,Y,Z) output
 // Feature reads come from L2 / Infinity Cache (each (b,v) map is re-read by many blocks), the output is
 // written exactly once.  The brick variant (unproject_brick.hip) replaces the L2 gather by LDS patches.
@@ -16,7 +16,7 @@
 
 namespace mvhmr {
 
-constexpr int kTileVox = 64;
+constexpr int kTileVox = 32;          // voxels per block: 128-B output runs; keeps the LDS tile at 33 KB (3 blocks per CU)
 constexpr int kGroupQuads = 64;      // 64 lanes x 4 channels
 constexpr int kGroupCh = 256;
 
@@ -30,7 +30,7 @@ __device__ __forceinline__ void build_records(TapRec *recs, const float *__restr
                                               long long N, int H, int W, int C4)
 {
     for (int idx = threadIdx.x; idx < kTileVox * V; idx += blockDim.x) {
-        const int v = idx >> 6, j = idx & 63;
+        const int v = idx / kTileVox, j = idx % kTileVox;
         long long n = n0 + j;
         n = n < N ? n : N - 1;       // tail voxels are computed and dropped
         const float *X = coords + ((long long)b * N + n) * 3;
@@ -113,13 +113,15 @@ k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const
     }
     __syncthreads();
 
-    // lane = voxel now: each store instruction writes 64 consecutive voxels of one channel
-    const long long n = n0 + lane;
+    // lanes 0..31 = voxels of the tile, the two half-waves take alternate channel quads: each store instruction writes
+    // two 128-B runs (32 consecutive voxels of two channels)
+    const int vl = lane & (kTileVox - 1), half = lane / kTileVox;
+    const long long n = n0 + vl;
     if (n < N) {
-        for (int qq = wave * 16; qq < wave * 16 + 16; ++qq) {
+        for (int qq = wave * 16 + half; qq < wave * 16 + 16; qq += 64 / kTileVox) {
             const int cq = cg * kGroupQuads + qq;
             if (cq >= Q) break;
-            const f32x4 t = tile[lane * tstride + qq];
+            const f32x4 t = tile[vl * tstride + qq];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = cq * 4 + i;
@@ -141,20 +143,21 @@ k_bwd_gather(const TO *__restrict__ grad_out, const TF *__restrict__ featT, cons
     const int V = VT > 0 ? VT : Vrt;
     extern __shared__ __align__(16) unsigned char smem[];
     TapRec *recs = reinterpret_cast<TapRec *>(smem);
-    float *gtile = reinterpret_cast<float *>(smem + sizeof(TapRec) * kTileVox * V);   // [256 ch][65]
+    float *gtile = reinterpret_cast<float *>(smem + sizeof(TapRec) * kTileVox * V);   // [256 ch][kTileVox + 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, cg = blockIdx.z;
     const long long n0 = (long long)blockIdx.x * kTileVox;
     const long long mapsz = (long long)H * W * C4;
 
     build_records(recs, proj, coords, b, V, n0, N, H, W, C4);
-    {   // grad_out tile, coalesced along voxels
-        const long long n = n0 + lane;
-        for (int r = wave * 64; r < wave * 64 + 64; ++r) {
+    {   // grad_out tile, coalesced along voxels: the two half-waves load alternate channels
+        const int vl = lane & (kTileVox - 1), half = lane / kTileVox;
+        const long long n = n0 + vl;
+        for (int r = wave * 64 + half; r < wave * 64 + 64; r += 64 / kTileVox) {
             const int c = cg * kGroupCh + r;
             float g = 0.f;
             if (c < C && n < N) g = to_f32<TO>(grad_out[((long long)b * C + c) * N + n]);
-            gtile[r * 65 + lane] = g;
+            gtile[r * (kTileVox + 1) + vl] = g;
         }
     }
     __syncthreads();
@@ -191,7 +194,7 @@ k_bwd_gather(const TO *__restrict__ grad_out, const TF *__restrict__ featT, cons
         if (n0 + j >= N) break;
         float g[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) g[i] = gtile[(i * 64 + lane) * 65 + j];
+        for (int i = 0; i < 4; ++i) g[i] = gtile[(i * 64 + lane) * (kTileVox + 1) + j];
 
         if constexpr (VT > 0) {
             float s[4][VT], ds[4][VT];
@@ -368,7 +371,7 @@ template <typename TF, typename TO, int METHOD>
 static hipError_t bwd_dispatch_v(const TO *go_, const TF *featT, const float *proj, const float *coords, float *gradT,
                                  const Problem &p, hipStream_t s)
 {
-    const size_t lds = sizeof(TapRec) * kTileVox * (size_t)p.V + sizeof(float) * kGroupCh * 65;
+    const size_t lds = sizeof(TapRec) * kTileVox * (size_t)p.V + sizeof(float) * kGroupCh * (kTileVox + 1);
     const dim3 grid((unsigned)((p.N + kTileVox - 1) / kTileVox), (unsigned)p.B, (unsigned)((p.C + kGroupCh - 1) / kGroupCh));
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
