@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--variant", default="auto", choices=("auto", "gather", "brick"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=1)
+    ap.add_argument("--cpu-sample-batch", type=int, default=8, help="samples of the workload timed on the host (about 15 s)")
     return ap.parse_args()
 
 
@@ -77,7 +77,7 @@ def cuboid_volume(batch, S, side=2500.0, seed=0):
     """aggregation.py:140-187 with theta = 0 (eval): origin-centred cuboid; the pivot is irrelevant at theta = 0."""
     g = np.stack(np.meshgrid(np.arange(S), np.arange(S), np.arange(S), indexing="ij"), -1).astype(np.float32)
     coords = (np.float32(-side / 2) + np.float32(side / (S - 1)) * g).astype(np.float32)
-    return np.broadcast_to(coords, (batch,) + coords.shape)
+    return np.ascontiguousarray(np.broadcast_to(coords, (batch,) + coords.shape))
 
 
 def frustum_stats(P, coords, H, W):
@@ -105,11 +105,18 @@ def main():
     if world != a.gpus and world > 1:
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    # one rank per GPU; on a box with fewer GPUs than ranks (rehearsals on a 1-GPU box) ranks share devices and the
+    # control-plane collectives fall back to gloo -- the data path has no collective either way
+    dev = torch.device("cuda", local_rank % n_dev)
+    torch.cuda.set_device(dev)
+    use_rccl = n_dev >= world
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        if use_rccl:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     B, S, C, V, HW = a.batch, a.grid, a.channels, a.views, a.feat
     N = S ** 3
@@ -121,7 +128,7 @@ def main():
     P_np = ring_projections(B, V, (HW, HW), seed=rank)
     coords_np = cuboid_volume(1, S)
     proj = torch.from_numpy(P_np).to(dev)
-    coords = torch.from_numpy(np.ascontiguousarray(coords_np)).to(dev).expand(B, S, S, S, 3).contiguous()
+    coords = torch.from_numpy(coords_np).to(dev).expand(B, S, S, S, 3).contiguous()
     out = torch.empty(B, C, S, S, S, device=dev, dtype=tdt)
 
     L = _capi.lib()
@@ -171,7 +178,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device=dev if use_rccl else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_step = elapsed / a.steps * 1e3
