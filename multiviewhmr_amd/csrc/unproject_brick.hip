@@ -60,11 +60,18 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     // XCDs work on the SAME sample at a time, each on a contiguous eighth of its bricks: neighbouring windows meet in one
     // L2, and the feature planes live across the chip are one or two samples (37.7 MB each at the north-star size) -- they
     // stay in the 256 MB Infinity Cache instead of being re-fetched from HBM (8 samples at once did not fit: 7.9 GB read).
-    const int share = (bricks_per_sample + 7) >> 3;                              // bricks of one sample per XCD
+    // Each XCD takes a compact tile of brick COLUMNS (all z): tiles_x x tiles_y = 8 tiles over the (x, y) brick grid.  A
+    // compact tile projects to a compact image region in every view, so an XCD pulls ~1/3 of each feature plane through
+    // its L2 instead of most of it (an x-slab covers the whole image for cameras that look along y).
+    const int nbx = bricks_per_sample / (nby * nbz);
+    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
+    const int tw = (nbx + tiles_x - 1) / tiles_x, th = (nby + tiles_y - 1) / tiles_y;   // tile size in brick columns
+    const int share = tw * th * nbz;                                             // work items of one sample per XCD
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int b = j / share, brick = xcd * share + j % share;
-    if (brick >= bricks_per_sample || b * bricks_per_sample >= total_blocks) return;
-    const int kz = brick % nbz, ky = (brick / nbz) % nby, kx = brick / (nbz * nby);
+    const int b = j / share, r = j % share;
+    const int kz = r % nbz, cy = (r / nbz) % th, cx = r / (nbz * th);
+    const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
+    if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
     const long long N = (long long)X * Y * Z;
     const int HW = H * W, nq = C >> 2;
 
@@ -225,7 +232,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
                              __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
-            __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, 18);   // nt sc1: the output must not displace the windows in L2
         };
         // one quad: all 4 * VT taps of quad q+1 go in flight, quad q is aggregated and stored under them, then the taps
         // are folded into the samples of quad q+1 (the old samples are dead by then: one sample array suffices)
@@ -299,7 +306,8 @@ hipError_t launch_v(const float4 *featK, const float *proj, const float *coords,
     auto kern = k_fwd_brick<METHOD, VT, kNT>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
-    const int grid = ((bps + 7) / 8) * 8 * p.B;                                   // (bricks per XCD per sample) x 8 XCDs x samples
+    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
+    const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;   // tile work items x 8 XCDs x samples
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total);
     return hipGetLastError();
 }
