@@ -45,6 +45,13 @@ __device__ __forceinline__ void build_records(TapRec *recs, const float *__restr
     }
 }
 
+// output stores bypass-ish the caches (nt): the volume is written once and must not displace the feature rows in L2
+__device__ __forceinline__ void store_streaming(float *p, float v) { __builtin_nontemporal_store(v, p); }
+__device__ __forceinline__ void store_streaming(__half *p, float v)
+{
+    __builtin_nontemporal_store(__half_as_ushort(__float2half_rn(v)), reinterpret_cast<unsigned short *>(p));
+}
+
 struct UTap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
 __device__ __forceinline__ UTap uniform_rec(const TapRec &r)
 {
@@ -125,7 +132,7 @@ k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int c = cq * 4 + i;
-                if (c < C) out[((long long)b * C + c) * N + n] = from_f32<TO>(t.v[i]);
+                if (c < C) store_streaming(&out[((long long)b * C + c) * N + n], t.v[i]);   // keep L2 for the features
             }
         }
     }
