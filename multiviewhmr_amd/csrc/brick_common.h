@@ -16,6 +16,12 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// workgroup barrier that waits for nothing: LDS reads of OTHER buffers may stay in flight across it
+__device__ __forceinline__ void bare_barrier()
+{
+    asm volatile("s_barrier" ::: "memory");
+}
+
 typedef __attribute__((address_space(3))) void lds_void_t;
 
 // LDS-DMA of 16 B per lane: lane l's bytes land at lds_dst + 16*l (lds_dst wave-uniform), read from base + voff[l].

@@ -201,22 +201,19 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // would break the counted vmcnt waits below -- the Makefile fails the build if this kernel uses scratch):
         // one view's taps (4 x b128) are in flight at a time; sub-step u reads view u of quad q+1, aggregates and
         // stores its share of quad q's channels meanwhile, then folds the taps into the next quad's samples.
-        f32x4 T[VT][4];                                                          // all taps of quad q+1, in flight
-        float s[4][VT];                                                          // samples of quad q
-        auto read_all = [&](int q) {
-            const int boff = ring(q);
-#pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                const int base = a0[v] + boff, row1 = base + ws16[v];
-                T[v][0] = lds_tap(smem, base); T[v][1] = lds_tap(smem, base + 16);
-                T[v][2] = lds_tap(smem, row1); T[v][3] = lds_tap(smem, row1 + 16);
-            }
+        f32x4 T[VT][4];                                                          // taps in flight / landed (next quad)
+        float s[4][VT];                                                          // samples of the quad being aggregated
+        auto read_view = [&](int q, int v) {
+            const int base = a0[v] + ring(q), row1 = base + ws16[v];
+            T[v][0] = lds_tap(smem, base); T[v][1] = lds_tap(smem, base + 16);
+            T[v][2] = lds_tap(smem, row1); T[v][3] = lds_tap(smem, row1 + 16);
         };
-        auto bilerp_all = [&]() {
+        auto fold_view = [&](int v) {
 #pragma unroll
-            for (int v = 0; v < VT; ++v)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s[i][v] = bilerp(T[v][0].v[i], T[v][1].v[i], T[v][2].v[i], T[v][3].v[i], w00[v], w01[v], w10[v], w11[v]);
+            for (int i = 0; i < 4; ++i) {
+                s[i][v] = bilerp(T[v][0].v[i], T[v][1].v[i], T[v][2].v[i], T[v][3].v[i], w00[v], w01[v], w10[v], w11[v]);
+                asm volatile("" : "+v"(s[i][v]));      // fold HERE: the optimiser would sink the FMAs to the aggregate and keep T live
+            }
         };
         // Stores: one buffer_store_dwordx4 per wave per quad.  A lane quad (4 consecutive z of one column) transposes its
         // 4 channels x 4 voxels in registers, so lane j writes channel j's 16 contiguous bytes; 8 quads of a column make a
@@ -234,32 +231,80 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                              __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
             __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, 18);   // nt sc1: the output must not displace the windows in L2
         };
-        // one quad: all 4 * VT taps of quad q+1 go in flight, quad q is aggregated and stored under them, then the taps
-        // are folded into the samples of quad q+1 (the old samples are dead by then: one sample array suffices)
-        auto quad_step = [&](int q) {
-            const bool more = q + 1 < nq;
+        // one quad.  On entry both halves of quad q's taps are in flight (or landed) in T; the samples s are dead.
+        // The taps of quad q+1 are requested half by half as soon as the registers of a half have been folded, so the LDS
+        // pipe has 2*VT..4*VT reads of this wave queued during EVERY phase (bilinear FMAs, barrier, DMA issue, aggregate,
+        // store) instead of idling while the VALU folds: LDS time and VALU time overlap instead of adding up.
+        // The barrier sits between "all waves have folded quad q" (its buffer is free for the DMA of quad q+nb) and the
+        // DMA issue; it is a bare s_barrier: the LDS reads in flight across it belong to quad q+1's buffer.
+        auto finish_quad = [&](int q) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
-            if (more) read_all(q + 1);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int c = 0; c < 4; ++c) res[c] = aggregate<METHOD, VT>(s[c]);
             store_quad(rs);
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) bilerp_all();
-            const bool issue = q + nb < nq;
-            if (issue) dma(q + nb);
-            if (q + 2 < nq) wait_vmcnt(nb == 3 ? 1 + (issue ? n_c : 0) : 0);
-            lds_barrier();
         };
 
         for (int q = 0; q < nb && q < nq; ++q) dma(q);
-        wait_vmcnt(nb == 3 && nq > 2 ? n_c : 0);                                 // quads 0 and 1 have landed
+        wait_vmcnt(0);
         lds_barrier();
-        read_all(0);
-        bilerp_all();
-        lds_barrier();                       // every wave is done with quad 0's buffer before anyone's DMA reuses it
+        // One quad per iteration.  On entry the taps of quad q are in flight (or landed) in T.  The taps of a view are
+        // folded into its sample and the SAME view of quad q+1 is requested at once, so the LDS pipe has this wave's
+        // reads queued during the folds, the barrier, the DMA issue, the aggregate and the store -- LDS time and VALU time
+        // overlap instead of adding up.  The last view is requested after the store: with all 4*VT taps in flight under
+        // the aggregate the kernel does not fit 128 registers.
+        // The barrier sits between "every wave has folded quad q" (its buffer is free for the DMA of quad q+nb) and the
+        // DMA issue.  It is a bare s_barrier: the reads in flight across it belong to quad q+1's buffer.
+        // The loops start at q = -1, an iteration that only requests quad 0: T has a single definition site, inside the
+        // loop (a second one in a prologue made the register allocator copy and spill the 4*VT tuples).
+#pragma unroll
+        for (int v = 0; v < VT; ++v)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) T[v][t] = f32x4{{0.f, 0.f, 0.f, 0.f}};
+        if (nb == 3) {
 #pragma nounroll
-        for (int q = 0; q < nq; ++q) quad_step(q);
+            for (int q = -1; q < nq; ++q) {
+                const int qn = q + 1 < nq ? q + 1 : q;                              // last quad: re-read (unused), no branch
+#pragma unroll
+                for (int v = 0; v < VT - 1; ++v) {
+                    fold_view(v);
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_view(qn, v);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                fold_view(VT - 1);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q >= 0) {
+                    wait_vmcnt(1);                                                 // this wave's DMA of quad q+2 (older than store q-1)
+                    bare_barrier();                                                // quad q is folded everywhere; quad q+2 is published
+                    if (q + 3 < nq) dma(q + 3);
+                    finish_quad(q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                read_view(qn, VT - 1);
+            }
+        } else {
+            // 2-deep ring: quad q+1 can only be requested after the barrier that frees quad q-1's buffer, so it is
+            // published one barrier later and all reads follow the barrier (rare: windows between a third and half
+            // of the pool)
+#pragma nounroll
+            for (int q = -1; q < nq; ++q) {
+                const int qn = q + 1 < nq ? q + 1 : q;
+#pragma unroll
+                for (int v = 0; v < VT; ++v) fold_view(v);
+                if (q >= 0) {
+                    wait_vmcnt(1);
+                    bare_barrier();                                                // quad q folded everywhere, quad q+1 published
+                }
+#pragma unroll
+                for (int v = 0; v < VT - 1; ++v) read_view(qn, v);
+                if (q >= 0) {
+                    if (q + 2 < nq) dma(q + 2);
+                    finish_quad(q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                read_view(qn, VT - 1);
+            }
+        }
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (clamped taps, zero weights outside)
         int o00[VT], o01[VT], o10[VT], o11[VT];
