@@ -67,7 +67,7 @@ __device__ __forceinline__ void quad_transpose(float (&r)[4], int lane)
     }
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n: wait until at most n vector-memory operations of this wave
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..20 (anything larger waits for everything): wait until at most n vector-memory operations of this wave
 // (loads, LDS-DMA and stores count together, in issue order) are still outstanding
 __device__ __forceinline__ void wait_vmcnt(int n)
 {
@@ -86,14 +86,36 @@ __device__ __forceinline__ void wait_vmcnt(int n)
     case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
     case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    case 17: asm volatile("s_waitcnt vmcnt(17)" ::: "memory"); break;
+    case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+    case 19: asm volatile("s_waitcnt vmcnt(19)" ::: "memory"); break;
+    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
+}
+
+// no-return integer add in LDS (ds_add_u32: ~4-6 cycles per wave instruction on gfx950; ds_add_f32: ~190)
+__device__ __forceinline__ void lds_add(int *p, int v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// floor(x + 0.5) as int32 in one instruction
+__device__ __forceinline__ int round_int(float x)
+{
+    int r;
+    asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
 }
 
 template <int VT>
 struct BrickShared {
     int bbox[VT][4];               // xmin, ymin, xmax, ymax of the nw taps (valid voxels only)
     float proj[VT][12];
+    int aux[4];                    // backward: block-wide max |ds| of the even / odd quad (float bits), tap multiplicity
 };
 
 __device__ __forceinline__ int wave_min(int x)

@@ -99,12 +99,12 @@ int variant_conflict(const mvhmr_unproject_desc *d, const Problem &p, int varian
 // the gradient can be accumulated straight into grad_features when that already is fp32 channels-last
 bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->feat_layout == MVHMR_LAYOUT_BVHWC && !p.feat_f16; }
 
-// The brick backward (LDS-privatised accumulation) only runs when asked for explicitly: measured 189 ms against 104 ms
-// for the gather backward at the north-star size -- ds_add_f32 costs ~116 cycles per wave instruction on gfx950 and the
-// kernel issues 64 of them per voxel and channel quad (profiles/r01_bwd_brick_pmc.txt).  AUTO keeps the gather backward.
+// The brick backward (window gradients accumulated in LDS in fixed point, then flushed with 256-B shaped float atomics)
+// is the default wherever the brick forward is: ~20 GB of global atomic traffic instead of the gather backward's 137 GB
+// (profiles/r01_bwd_*).  variant = gather keeps the gather backward.
 bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant == MVHMR_VARIANT_BRICK && brick_supported(p);
+    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_supported(p);
 }
 
 int check_ws(void *ws, size_t have, size_t need)

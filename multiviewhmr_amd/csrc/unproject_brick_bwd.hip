@@ -100,7 +100,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
     constexpr int cap = ((kBwdLdsBytes - 2 * kZeroBytes - 16 * kZeroSlots) / 48) & ~63;
     constexpr int buf_bytes = kZeroBytes + cap * 16;
     constexpr int plane_floats = kZeroSlots + cap;
-    float *const gplanes = reinterpret_cast<float *>(smem + 2 * buf_bytes);
+    int *const iplanes = reinterpret_cast<int *>(smem + 2 * buf_bytes);
     const bool fits = used <= cap && nch[VT] <= kMaxChunks * NW && max_stride + 2 <= kZeroSlots;
     const float4 *const fk = featK + (long long)b * VT * nq * HW;
     float *const gk = gradK + (long long)b * VT * nq * HW * 4;
@@ -111,7 +111,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
     if (fits) {
         for (int i = tid; i < kZeroSlots * 2; i += NT)
             *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = tid; i < 4 * plane_floats; i += NT) gplanes[i] = 0.f;
+        for (int i = tid; i < 4 * plane_floats; i += NT) iplanes[i] = 0;
+        if (tid < 4) sh->aux[tid] = 0;
 
         int a0[VT], ws16[VT], ga[VT];
 #pragma unroll
@@ -156,6 +157,25 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
         };
 
         dma(0);
+        // ---- most taps any window pixel receives from this brick (once per brick): sizes the fixed-point headroom
+        lds_barrier();                                                           // planes are zero
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            int *p = iplanes + ga[v];
+            lds_add(p, 1); lds_add(p + 1, 1); lds_add(p + ws[v], 1); lds_add(p + ws[v] + 1, 1);
+        }
+        lds_barrier();
+        {
+            int m = 1;
+            for (int i = tid; i < used; i += NT) { const int c = iplanes[kZeroSlots + i]; m = c > m ? c : m; }
+            m = wave_max(m);
+            if (lane == 0) atomicMax(&sh->aux[2], m);
+        }
+        lds_barrier();
+        // headroom: the window sums stay below 2^30 when every contribution is below 2^hbits
+        const int cmax = uniform(sh->aux[2]);
+        const int hbits = 30 - (cmax <= 1 ? 0 : 32 - __builtin_clz(cmax - 1));   // 30 - ceil(log2(cmax))
+        for (int i = tid; i < plane_floats; i += NT) iplanes[i] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
 #pragma nounroll
@@ -178,25 +198,50 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                 for (int i = 0; i < 4; ++i) s[i][v] = bilerp(ta.v[i], tb.v[i], tc.v[i], td.v[i], w00[v], w01[v], w10[v], w11[v]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // Jacobian of the aggregate, then scatter into the LDS gradient window
+            // Jacobian of the aggregate for the whole quad, and the largest |ds| of the block: LDS float atomics run at
+            // ~190 cycles per wave instruction on gfx950, integer ones at ~4-6, so the window is accumulated in fixed
+            // point: contributions are scaled by a power of two chosen per (brick, quad) from the block-wide max |ds|
+            // (weights are <= 1) and the brick's tap multiplicity, rounded to int32 and added with ds_add_u32.
+            float ds[4][VT];
+            float big = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {                                        // one channel at a time (fenced: registers)
-                __builtin_amdgcn_sched_barrier(0);
-                float ds[VT];
-                aggregate_grad<METHOD, VT>(s[i], g[i], ds);
-                float *pl = gplanes + i * plane_floats;
+            for (int i = 0; i < 4; ++i) {
+                aggregate_grad<METHOD, VT>(s[i], g[i], ds[i]);
 #pragma unroll
-                for (int v = 0; v < VT; ++v) {
-                    float *p = pl + ga[v];
-                    atomicAdd(p, ds[v] * w00[v]);
-                    atomicAdd(p + 1, ds[v] * w01[v]);
-                    atomicAdd(p + ws[v], ds[v] * w10[v]);
-                    atomicAdd(p + ws[v] + 1, ds[v] * w11[v]);
+                for (int v = 0; v < VT; ++v) big = fmaxf(big, fabsf(ds[i][v]));
+            }
+            big = __builtin_bit_cast(float, wave_max(__builtin_bit_cast(int, big)));   // non-negative floats order as ints
+            if (lane == 0) atomicMax(&sh->aux[q & 1], __builtin_bit_cast(int, big));
+            lds_barrier();                                                       // max published; planes zeroed by the last flush
+            const int bbits = uniform(sh->aux[q & 1]);
+            // 2^e > max |ds|  ->  scale = 2^(hbits - e): |ds * w * scale| < 2^hbits.  Exponent clamped to normal floats.
+            const int e = ((bbits >> 23) & 0xff) - 126;
+            int se = hbits - e + 127;
+            se = se < 1 ? 1 : (se > 254 ? 254 : se);
+            const float scale = bbits == 0 ? 0.f : __builtin_bit_cast(float, se << 23);
+            const float inv_scale = bbits == 0 ? 0.f : __builtin_bit_cast(float, (254 - se) << 23);
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                // two address registers per view (tap row 0 / row 1); planes and the +1 column are immediate offsets.
+                // Opaque to the optimiser: hoisted out of the loop they become 32 pinned registers and the kernel spills
+                int r0 = ga[v] * 4;
+                asm volatile("" : "+v"(r0));
+                const int r1 = r0 + ws[v] * 4;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float d = ds[i][v] * scale;
+                    int *p0 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r0);
+                    int *p1 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r1);
+                    lds_add(p0, round_int(d * w00[v]));
+                    lds_add(p0 + 1, round_int(d * w01[v]));
+                    lds_add(p1, round_int(d * w10[v]));
+                    lds_add(p1 + 1, round_int(d * w11[v]));
                 }
             }
             lds_barrier();                                                       // every add of this quad has landed in LDS
             // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction
             float *gq = gk + (long long)q * HW * 4;
+            int n_at = 0;                                                        // atomic instructions this wave issues for this quad
 #pragma unroll
             for (int r = 0; r < kMaxChunks; ++r) {
                 if (l_dst[r] < 0) continue;
@@ -204,14 +249,19 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                 for (int jj = 0; jj < 4; ++jj) {
                     const int srcl = 16 * jj + (lane >> 2), ch = lane & 3;
                     const unsigned off = (unsigned)__shfl((int)g_off[r], srcl);    // byte offset of that slot's pixel (view base included) | live
-                    const unsigned lv = off & 1u;
-                    float *pl = gplanes + ch * plane_floats + c_slot[r] + srcl;
-                    const float val = *pl;
-                    *pl = 0.f;                                                    // ready for the next quad
-                    if (lv && val != 0.f) atomicAdd(gq + (off >> 2) + ch, val);
+                    int *pl = iplanes + ch * plane_floats + c_slot[r] + srcl;
+                    const int iv = *pl;
+                    *pl = 0;                                                      // ready for the next quad
+                    const bool add = (off & 1u) && iv != 0;
+                    if (__builtin_amdgcn_ballot_w64(add) != 0) {                   // wave-uniform: the instruction is issued or not
+                        if (add) atomicAdd(gq + (off >> 2) + ch, (float)iv * inv_scale);
+                        ++n_at;
+                    }
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     // the next quad's feature window has landed
+            if (tid == 0) sh->aux[q & 1] = 0;                                    // every wave read it before the last barrier
+            // the next quad's feature window (requested before this quad's atomics) has landed; the atomics stay in flight
+            wait_vmcnt(n_at);
             lds_barrier();
         }
     } else {
