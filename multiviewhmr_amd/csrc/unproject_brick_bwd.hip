@@ -26,6 +26,52 @@ namespace mvhmr {
 //   gradient plane = (kZeroSlots + cap) floats; the first kZeroSlots only ever receive +0 (samples that are identically zero)
 constexpr int kBwdLdsBytes = 160 * 1024 - 1024;
 
+// Slow path of k_bwd_brick for one voxel: global float atomics per tap (bricks whose windows do not fit the LDS pool).
+template <int METHOD, int VT>
+__device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const float *gobase, float *gk, const float (*proj)[12],
+                                                         const float *Xp, unsigned vox, long long N, int nq, int H, int W)
+{
+    const int HW = H * W;
+    float w00[VT], w01[VT], w10[VT], w11[VT];
+    int o00[VT], o01[VT], o10[VT], o11[VT];
+    const float c0 = Xp[0], c1 = Xp[1], c2 = Xp[2];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        const Taps t = make_taps(proj[v], c0, c1, c2, H, W);
+        w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
+        const int x0 = t.rx0 < 0 ? 0 : t.rx0, y0 = t.ry0 < 0 ? 0 : t.ry0;
+        const int x1 = t.rx0 + 1 > W - 1 ? W - 1 : t.rx0 + 1, y1 = t.ry0 + 1 > H - 1 ? H - 1 : t.ry0 + 1;
+        const int base = (v * nq) * HW;
+        o00[v] = base + y0 * W + x0; o01[v] = base + y0 * W + x1; o10[v] = base + y1 * W + x0; o11[v] = base + y1 * W + x1;
+    }
+    for (int q = 0; q < nq; ++q) {
+        const float4 *src = fk + (long long)q * HW;
+        float *gq = gk + (long long)q * HW * 4;
+        float s[4][VT];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const float4 a = src[o00[v]], bb = src[o01[v]], c = src[o10[v]], d = src[o11[v]];
+            s[0][v] = bilerp(a.x, bb.x, c.x, d.x, w00[v], w01[v], w10[v], w11[v]);
+            s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[v], w01[v], w10[v], w11[v]);
+            s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]);
+            s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float g = gobase[(long long)(q * 4 + i) * N + vox];
+            float ds[VT];
+            aggregate_grad<METHOD, VT>(s[i], g, ds);
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                if (w00[v] != 0.f) atomicAdd(gq + (long long)o00[v] * 4 + i, ds[v] * w00[v]);
+                if (w01[v] != 0.f) atomicAdd(gq + (long long)o01[v] * 4 + i, ds[v] * w01[v]);
+                if (w10[v] != 0.f) atomicAdd(gq + (long long)o10[v] * 4 + i, ds[v] * w10[v]);
+                if (w11[v] != 0.f) atomicAdd(gq + (long long)o11[v] * 4 + i, ds[v] * w11[v]);
+            }
+        }
+    }
+}
+
 template <int METHOD, int VT, int NT>
 __global__ void __launch_bounds__(NT)
 k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out, const float *__restrict__ proj,
@@ -156,7 +202,15 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                 if (l_dst[r] >= 0) glds16(src, g_off[r] & ~15u, lds_base + (unsigned)uniform(l_dst[r] + boff));
         };
 
+        // grad_out of this voxel's 4 channels (128-B runs per channel across the wave), one quad ahead
+        float gn[4];
+        auto load_g = [&](int q) {
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gobase) + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)voxb, (int)(i * chan_bytes), 0));
+        };
         dma(0);
+        load_g(0);
         // ---- most taps any window pixel receives from this brick (once per brick): sizes the fixed-point headroom
         lds_barrier();                                                           // planes are zero
 #pragma unroll
@@ -180,12 +234,16 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
         lds_barrier();
 #pragma nounroll
         for (int q = 0; q < nq; ++q) {
-            if (q + 1 < nq) dma(q + 1);
-            // grad_out of this voxel's 4 channels (128-B runs per channel across the wave)
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gobase) + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
+            // Requests of the NEXT quad go out before this quad's flush: a CU's vector-memory pipe is in order, and the
+            // ~160 atomic instructions of a flush take ~8 us to drain at the chip-wide atomic rate -- loads queued behind
+            // them would stall the next quad's arithmetic, which is what hides that drain.
             float g[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)voxb, (int)(i * chan_bytes), 0));
+            for (int i = 0; i < 4; ++i) g[i] = gn[i];
+            if (q + 1 < nq) {
+                dma(q + 1);
+                load_g(q + 1);
+            }
             // re-sample
             const int boff = (q & 1) * buf_bytes;
             float s[4][VT];
@@ -265,41 +323,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
             lds_barrier();
         }
     } else {
-        // ---- windows do not fit: scatter straight to the accumulator (global atomics per tap)
-        int o00[VT], o01[VT], o10[VT], o11[VT];
-#pragma unroll
-        for (int v = 0; v < VT; ++v) {
-            const int x0 = tx[v] < 0 ? 0 : tx[v], y0 = ty[v] < 0 ? 0 : ty[v];
-            const int x1 = tx[v] + 1 > W - 1 ? W - 1 : tx[v] + 1, y1 = ty[v] + 1 > H - 1 ? H - 1 : ty[v] + 1;
-            const int base = (v * nq) * HW;
-            o00[v] = base + y0 * W + x0; o01[v] = base + y0 * W + x1; o10[v] = base + y1 * W + x0; o11[v] = base + y1 * W + x1;
-        }
-        for (int q = 0; q < nq; ++q) {
-            const float4 *src = fk + (long long)q * HW;
-            float *gq = gk + (long long)q * HW * 4;
-            float s[4][VT];
-#pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                const float4 a = src[o00[v]], bb = src[o01[v]], c = src[o10[v]], d = src[o11[v]];
-                s[0][v] = bilerp(a.x, bb.x, c.x, d.x, w00[v], w01[v], w10[v], w11[v]);
-                s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[v], w01[v], w10[v], w11[v]);
-                s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]);
-                s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]);
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const float g = gobase[(long long)(q * 4 + i) * N + vox];
-                float ds[VT];
-                aggregate_grad<METHOD, VT>(s[i], g, ds);
-#pragma unroll
-                for (int v = 0; v < VT; ++v) {
-                    if (w00[v] != 0.f) atomicAdd(gq + (long long)o00[v] * 4 + i, ds[v] * w00[v]);
-                    if (w01[v] != 0.f) atomicAdd(gq + (long long)o01[v] * 4 + i, ds[v] * w01[v]);
-                    if (w10[v] != 0.f) atomicAdd(gq + (long long)o10[v] * 4 + i, ds[v] * w10[v]);
-                    if (w11[v] != 0.f) atomicAdd(gq + (long long)o11[v] * 4 + i, ds[v] * w11[v]);
-                }
-            }
-        }
+        // ---- windows do not fit: scatter straight to the accumulator (its own function: keeps its registers -- 16 tap
+        // offsets on top of the weights -- out of the fast path's allocation, which otherwise spills in the quad loop)
+        bwd_brick_slow<METHOD, VT>(fk, gobase, gk, sh->proj, coords + ((long long)b * N + vox) * 3, vox, N, nq, H, W);
     }
 }
 
