@@ -216,7 +216,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             int *p = iplanes + ga[v];
-            lds_add(p, 1); lds_add(p + 1, 1); lds_add(p + ws[v], 1); lds_add(p + ws[v] + 1, 1);
+            if ((valid >> v) & 1u) { lds_add(p, 1); lds_add(p + 1, 1); lds_add(p + ws[v], 1); lds_add(p + ws[v] + 1, 1); }
         }
         lds_barrier();
         {
@@ -232,20 +232,22 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
         for (int i = tid; i < plane_floats; i += NT) iplanes[i] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         lds_barrier();
-#pragma nounroll
-        for (int q = 0; q < nq; ++q) {
-            // Requests of the NEXT quad go out before this quad's flush: a CU's vector-memory pipe is in order, and the
-            // ~160 atomic instructions of a flush take ~8 us to drain at the chip-wide atomic rate -- loads queued behind
-            // them would stall the next quad's arithmetic, which is what hides that drain.
+        // ---- quad loop, two barriers per quad:
+        //   accumulate quad q   64 ds_add_u32 per lane, fire and forget (ds of quad q was computed one iteration earlier)
+        //   prepare quad q+1    request the window / grad_out of quad q+2, re-sample quad q+1, Jacobian -> ds, publish the
+        //                       block-wide max |ds|: the LDS pipe works off the adds underneath this arithmetic
+        //   barrier             adds of quad q complete, max of quad q+1 known
+        //   flush quad q        window -> global float atomics (256 contiguous bytes per instruction), planes zeroed
+        //   barrier             planes zero, window q+2 landed (counted wait: the flush atomics stay in flight)
+        // Requests go out BEFORE the flush: a CU's vector-memory pipe is in order and a flush's ~160 atomic instructions take
+        // microseconds to drain -- loads queued behind them would stall the next quad.
+        float ds[4][VT];
+        auto prepare = [&](int q) {                                              // ds of quad q from window buffer q & 1 and gn
+            const int boff = (q & 1) * buf_bytes;
             float g[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) g[i] = gn[i];
-            if (q + 1 < nq) {
-                dma(q + 1);
-                load_g(q + 1);
-            }
-            // re-sample
-            const int boff = (q & 1) * buf_bytes;
+            if (q + 1 < nq) load_g(q + 1);
             float s[4][VT];
 #pragma unroll
             for (int v = 0; v < VT; ++v) {                                       // one view at a time: 16 tap registers, not 64
@@ -256,11 +258,6 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                 for (int i = 0; i < 4; ++i) s[i][v] = bilerp(ta.v[i], tb.v[i], tc.v[i], td.v[i], w00[v], w01[v], w10[v], w11[v]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // Jacobian of the aggregate for the whole quad, and the largest |ds| of the block: LDS float atomics run at
-            // ~190 cycles per wave instruction on gfx950, integer ones at ~4-6, so the window is accumulated in fixed
-            // point: contributions are scaled by a power of two chosen per (brick, quad) from the block-wide max |ds|
-            // (weights are <= 1) and the brick's tap multiplicity, rounded to int32 and added with ds_add_u32.
-            float ds[4][VT];
             float big = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -270,7 +267,16 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
             }
             big = __builtin_bit_cast(float, wave_max(__builtin_bit_cast(int, big)));   // non-negative floats order as ints
             if (lane == 0) atomicMax(&sh->aux[q & 1], __builtin_bit_cast(int, big));
-            lds_barrier();                                                       // max published; planes zeroed by the last flush
+        };
+        if (nq > 1) dma(1);
+        prepare(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // window 1 has landed
+        lds_barrier();
+#pragma nounroll
+        for (int q = 0; q < nq; ++q) {
+            // LDS float atomics run at ~190 cycles per wave instruction on gfx950, integer ones at ~4-6, so the window is
+            // accumulated in fixed point: contributions are scaled by a power of two chosen per (brick, quad) from the
+            // block-wide max |ds| (weights are <= 1) and the brick's tap multiplicity, rounded to int32, ds_add_u32.
             const int bbits = uniform(sh->aux[q & 1]);
             // 2^e > max |ds|  ->  scale = 2^(hbits - e): |ds * w * scale| < 2^hbits.  Exponent clamped to normal floats.
             const int e = ((bbits >> 23) & 0xff) - 126;
@@ -285,6 +291,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                 int r0 = ga[v] * 4;
                 asm volatile("" : "+v"(r0));
                 const int r1 = r0 + ws[v] * 4;
+                // lanes whose sample is identically zero add nothing: parked on the zero slot they would all hit ONE
+                // address, and same-address LDS atomics serialise (2 cycles per lane)
+                if ((valid >> v) & 1u)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float d = ds[i][v] * scale;
@@ -296,7 +305,10 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                     lds_add(p1 + 1, round_int(d * w11[v]));
                 }
             }
-            lds_barrier();                                                       // every add of this quad has landed in LDS
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 2 < nq) dma(q + 2);                                          // into the buffer quad q was sampled from
+            if (q + 1 < nq) prepare(q + 1);
+            lds_barrier();                                                       // adds of quad q landed; max of quad q+1 published
             // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction
             float *gq = gk + (long long)q * HW * 4;
             int n_at = 0;                                                        // atomic instructions this wave issues for this quad
@@ -317,8 +329,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                     }
                 }
             }
-            if (tid == 0) sh->aux[q & 1] = 0;                                    // every wave read it before the last barrier
-            // the next quad's feature window (requested before this quad's atomics) has landed; the atomics stay in flight
+            if (tid == 0) sh->aux[q & 1] = 0;                                    // read by every wave before the barrier above
+            // window q+2 and grad_out q+2 (requested before this quad's atomics) have landed; the atomics stay in flight
             wait_vmcnt(n_at);
             lds_barrier();
         }
