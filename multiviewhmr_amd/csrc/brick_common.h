@@ -1,5 +1,6 @@
 // Helpers shared by the brick kernels (forward: unproject_brick.hip, backward: unproject_brick_bwd.hip).
 #pragma once
+#include <type_traits>
 #include "device_common.h"
 
 namespace mvhmr {
@@ -115,7 +116,7 @@ template <int VT>
 struct BrickShared {
     int bbox[VT][4];               // xmin, ymin, xmax, ymax of the nw taps (valid voxels only)
     float proj[VT][12];
-    int aux[4];                    // backward: block-wide max |ds| of the even / odd quad (float bits), tap multiplicity
+    int aux[9];                    // backward: block-wide max |ds| per channel of the even / odd quad (float bits); [8] tap multiplicity
 };
 
 __device__ __forceinline__ int wave_min(int x)
@@ -129,6 +130,24 @@ __device__ __forceinline__ int wave_max(int x)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { const int y = __shfl_xor(x, m); x = y > x ? y : x; }
     return x;
+}
+
+// max over the wave without LDS traffic (the __shfl_xor form goes through ds_bpermute): four DPP steps leave every lane
+// of a 16-lane row with the row's max, four readlanes and scalar max finish.  Result wave-uniform.
+__device__ __forceinline__ int wave_max_dpp(int x)
+{
+    auto step = [](int v, auto ctrl) {
+        const int y = __builtin_amdgcn_update_dpp(v, v, decltype(ctrl)::value, 0xF, 0xF, false);
+        return y > v ? y : v;
+    };
+    x = step(x, std::integral_constant<int, 0xB1>{});      // quad_perm [1,0,3,2]
+    x = step(x, std::integral_constant<int, 0x4E>{});      // quad_perm [2,3,0,1]
+    x = step(x, std::integral_constant<int, 0x141>{});     // row_half_mirror
+    x = step(x, std::integral_constant<int, 0x140>{});     // row_mirror
+    const int a = __builtin_amdgcn_readlane(x, 0), b = __builtin_amdgcn_readlane(x, 16);
+    const int c = __builtin_amdgcn_readlane(x, 32), d = __builtin_amdgcn_readlane(x, 48);
+    const int ab = a > b ? a : b, cd = c > d ? c : d;
+    return ab > cd ? ab : cd;
 }
 
 }  // namespace mvhmr

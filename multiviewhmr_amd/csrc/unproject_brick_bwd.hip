@@ -158,7 +158,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
         for (int i = tid; i < kZeroSlots * 2; i += NT)
             *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = tid; i < 4 * plane_floats; i += NT) iplanes[i] = 0;
-        if (tid < 4) sh->aux[tid] = 0;
+        if (tid < 9) sh->aux[tid] = 0;
 
         int a0[VT], ws16[VT], ga[VT];
 #pragma unroll
@@ -223,11 +223,11 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
             int m = 1;
             for (int i = tid; i < used; i += NT) { const int c = iplanes[kZeroSlots + i]; m = c > m ? c : m; }
             m = wave_max(m);
-            if (lane == 0) atomicMax(&sh->aux[2], m);
+            if (lane == 0) atomicMax(&sh->aux[8], m);
         }
         lds_barrier();
         // headroom: the window sums stay below 2^30 when every contribution is below 2^hbits
-        const int cmax = uniform(sh->aux[2]);
+        const int cmax = uniform(sh->aux[8]);
         const int hbits = 30 - (cmax <= 1 ? 0 : 32 - __builtin_clz(cmax - 1));   // 30 - ceil(log2(cmax))
         for (int i = tid; i < plane_floats; i += NT) iplanes[i] = 0;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -258,15 +258,15 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                 for (int i = 0; i < 4; ++i) s[i][v] = bilerp(ta.v[i], tb.v[i], tc.v[i], td.v[i], w00[v], w01[v], w10[v], w11[v]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            float big = 0.f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 aggregate_grad<METHOD, VT>(s[i], g[i], ds[i]);
+                float big = 0.f;
 #pragma unroll
                 for (int v = 0; v < VT; ++v) big = fmaxf(big, fabsf(ds[i][v]));
+                const int bb = wave_max_dpp(__builtin_bit_cast(int, big));       // non-negative floats order as ints
+                if (lane == 0) atomicMax(&sh->aux[(q & 1) * 4 + i], bb);            // one scale per channel of the quad
             }
-            big = __builtin_bit_cast(float, wave_max(__builtin_bit_cast(int, big)));   // non-negative floats order as ints
-            if (lane == 0) atomicMax(&sh->aux[q & 1], __builtin_bit_cast(int, big));
         };
         if (nq > 1) dma(1);
         prepare(0);
@@ -277,13 +277,18 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
             // LDS float atomics run at ~190 cycles per wave instruction on gfx950, integer ones at ~4-6, so the window is
             // accumulated in fixed point: contributions are scaled by a power of two chosen per (brick, quad) from the
             // block-wide max |ds| (weights are <= 1) and the brick's tap multiplicity, rounded to int32, ds_add_u32.
-            const int bbits = uniform(sh->aux[q & 1]);
-            // 2^e > max |ds|  ->  scale = 2^(hbits - e): |ds * w * scale| < 2^hbits.  Exponent clamped to normal floats.
-            const int e = ((bbits >> 23) & 0xff) - 126;
-            int se = hbits - e + 127;
-            se = se < 1 ? 1 : (se > 254 ? 254 : se);
-            const float scale = bbits == 0 ? 0.f : __builtin_bit_cast(float, se << 23);
-            const float inv_scale = bbits == 0 ? 0.f : __builtin_bit_cast(float, (254 - se) << 23);
+            // 2^e > max |ds| of the channel  ->  scale = 2^(hbits - e): |ds * w * scale| < 2^hbits.  Exponent clamped to normal
+            // floats; an all-zero channel adds nothing.
+            float scale[4], inv_scale[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int bbits = uniform(sh->aux[(q & 1) * 4 + i]);
+                const int e = ((bbits >> 23) & 0xff) - 126;
+                int se = hbits - e + 127;
+                se = se < 1 ? 1 : (se > 254 ? 254 : se);
+                scale[i] = bbits == 0 ? 0.f : __builtin_bit_cast(float, se << 23);
+                inv_scale[i] = bbits == 0 ? 0.f : __builtin_bit_cast(float, (254 - se) << 23);
+            }
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
                 // two address registers per view (tap row 0 / row 1); planes and the +1 column are immediate offsets.
@@ -296,7 +301,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                 if ((valid >> v) & 1u)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float d = ds[i][v] * scale;
+                    const float d = ds[i][v] * scale[i];
                     int *p0 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r0);
                     int *p1 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r1);
                     lds_add(p0, round_int(d * w00[v]));
@@ -312,6 +317,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
             // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction
             float *gq = gk + (long long)q * HW * 4;
             int n_at = 0;                                                        // atomic instructions this wave issues for this quad
+            const float inv_ch = (lane & 2) ? ((lane & 1) ? inv_scale[3] : inv_scale[2]) : ((lane & 1) ? inv_scale[1] : inv_scale[0]);
 #pragma unroll
             for (int r = 0; r < kMaxChunks; ++r) {
                 if (l_dst[r] < 0) continue;
@@ -324,12 +330,12 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
                     *pl = 0;                                                      // ready for the next quad
                     const bool add = (off & 1u) && iv != 0;
                     if (__builtin_amdgcn_ballot_w64(add) != 0) {                   // wave-uniform: the instruction is issued or not
-                        if (add) atomicAdd(gq + (off >> 2) + ch, (float)iv * inv_scale);
+                        if (add) atomicAdd(gq + (off >> 2) + ch, (float)iv * inv_ch);
                         ++n_at;
                     }
                 }
             }
-            if (tid == 0) sh->aux[q & 1] = 0;                                    // read by every wave before the barrier above
+            if (tid < 4) sh->aux[(q & 1) * 4 + tid] = 0;                         // read by every wave before the barrier above
             // window q+2 and grad_out q+2 (requested before this quad's atomics) have landed; the atomics stay in flight
             wait_vmcnt(n_at);
             lds_barrier();

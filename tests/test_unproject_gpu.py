@@ -146,10 +146,16 @@ def test_brick_variant_vs_oracle(shape, mode, gpu):
     assert float((out - gat).abs().max()) <= 2e-6         # same arithmetic, two kernels
 
 
+@pytest.mark.parametrize("shape", [
+    dict(B=2, V=4, C=8, H=48, W=48, vol=(8, 8, 32)),          # windows fit: fixed-point LDS accumulation + flush
+    dict(B=1, V=2, C=12, H=32, W=32, vol=(4, 8, 64)),         # odd number of quads, two z bricks per column
+    dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)),        # windows overflow the LDS pool: out-of-line global-atomic path
+    dict(B=1, V=4, C=16, H=12, W=12, vol=(8, 8, 32)),         # tiny maps: most taps outside the image, lanes masked out of the adds
+])
 @pytest.mark.parametrize("mode", MODES)
-def test_brick_backward_vs_oracle(mode, gpu):
-    """the (experimental) LDS-privatised backward, reachable with variant='brick'"""
-    feats, proj, coords = _ring_problem(B=2, V=4, C=8, H=48, W=48, vol=(8, 8, 32), seed=31)
+def test_brick_backward_vs_oracle(shape, mode, gpu):
+    """the brick backward (window gradients accumulated in LDS in fixed point), the default where the brick forward runs"""
+    feats, proj, coords = _ring_problem(seed=31, **shape)
     f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
     p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
     out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick")
@@ -157,6 +163,25 @@ def test_brick_backward_vs_oracle(mode, gpu):
     out.backward(torch.from_numpy(go).to(gpu))
     gref = cport.backward(go, feats, proj, coords, mode)
     assert float(np.abs(f.grad.cpu().numpy() - gref).max()) <= TOL * max(1.0, float(np.abs(gref).max()) / 8.0)
+
+
+def test_brick_backward_keeps_per_channel_precision(gpu):
+    """the fixed-point window accumulation scales every channel by its own power of two: channels of one quad that differ
+    by 20 orders of magnitude (and an all-zero one) each keep fp32-like relative accuracy"""
+    feats, proj, coords = _ring_problem(B=1, V=4, C=8, H=48, W=48, vol=(8, 8, 32), seed=77)
+    f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    out = aggregation.unprojection(f, p, c, variant="brick")
+    mag = np.array([1e-12, 1e8, 1.0, 0.0, 3e-30, 1e20, 1e-3, 7.0], np.float32)
+    go = np.random.default_rng(8).standard_normal(tuple(out.shape), dtype=np.float32) * mag[None, :, None, None, None]
+    out.backward(torch.from_numpy(go).to(gpu))
+    gref = cport.backward(go, feats, proj, coords, "softmax")
+    got = f.grad.cpu().numpy()
+    for ch in range(8):
+        ref_c, got_c = gref[:, :, ch], got[:, :, ch]
+        scale = float(np.abs(ref_c).max())
+        assert float(np.abs(got_c - ref_c).max()) <= 2e-5 * scale, (ch, scale)
+    assert not got[:, :, 3].any()
 
 
 def test_brick_variant_with_cameras_inside_the_volume(gpu):
