@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--variant", default="auto", choices=("auto", "gather", "brick"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--no-backward", action="store_true", help="skip the (untimed-for-`value`) backward measurement")
     ap.add_argument("--cpu-sample-batch", type=int, default=8, help="samples of the workload timed on the host (about 15 s)")
     return ap.parse_args()
 
@@ -206,6 +207,29 @@ def main():
                      "layout_pass_ms": round(k_layout, 4), "algorithmic_bytes": alg_bytes,
                      "step_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+
+    # Backward (gradient w.r.t. the features), reported beside the headline: SURVEY.md 8(d) quotes fwd and fwd+bwd
+    # separately.  Outside the timed region of `value`; grad_out = the forward output (same shape, realistic values).
+    if rank == 0 and world == 1 and not a.no_backward and a.dtype == "f32":
+        wsb = L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc))
+        ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+        gfeat = torch.empty_like(feats)
+        eb = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        n_b = 5
+        for it in range(n_b + 1):
+            if it == 1: eb[0].record()
+            _capi.check(L.mvhmr_unproject_backward(ctypes.byref(desc), vp(out.data_ptr()), vp(feats.data_ptr()), vp(proj.data_ptr()),
+                                                   vp(coords.data_ptr()), vp(gfeat.data_ptr()), vp(ws.data_ptr()), wsb, stream))
+        eb[1].record()
+        torch.cuda.synchronize()
+        ms_b = eb[0].elapsed_time(eb[1]) / n_b
+        # grad_out + features (re-read) + coords + proj + grad_features
+        bwd_bytes = B * C * N * esz + B * V * C * HW * HW * esz + B * N * 12 + B * V * 48 + B * V * C * HW * HW * 4
+        result["backward"] = {"ms": round(ms_b, 3), "value": round(B * N * V / (ms_b * 1e-3) / 1e6, 1), "unit": "Mvoxel*views/s",
+                              "algorithmic_bytes": bwd_bytes, "frac": round(bwd_bytes / (ms_b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                              "includes": "layout pass of the features + gradient clear + kernel (one C-ABI call)",
+                              "fwd_plus_bwd_ms": round(ms_step + ms_b, 3)}
+        del ws, gfeat
 
     if rank == 0:
         traffic = os.path.join(ROOT, "profiles", "traffic_latest.json")
