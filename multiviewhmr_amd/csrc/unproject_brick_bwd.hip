@@ -234,30 +234,35 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
         lds_barrier();
         // ---- quad loop, two barriers per quad:
         //   accumulate quad q   64 ds_add_u32 per lane, fire and forget (ds of quad q was computed one iteration earlier)
-        //   prepare quad q+1    request the window / grad_out of quad q+2, re-sample quad q+1, Jacobian -> ds, publish the
-        //                       block-wide max |ds|: the LDS pipe works off the adds underneath this arithmetic
+        //   (first)             re-sample quad q+1 (LDS reads ahead of the adds: the LDS pipe is in order)
+        //   then                request the window / grad_out of quad q+2; Jacobian of quad q+1 -> ds, publish the block-wide
+        //                       max |ds| per channel: the LDS pipe works off the adds underneath this arithmetic
         //   barrier             adds of quad q complete, max of quad q+1 known
         //   flush quad q        window -> global float atomics (256 contiguous bytes per instruction), planes zeroed
         //   barrier             planes zero, window q+2 landed (counted wait: the flush atomics stay in flight)
         // Requests go out BEFORE the flush: a CU's vector-memory pipe is in order and a flush's ~160 atomic instructions take
         // microseconds to drain -- loads queued behind them would stall the next quad.
-        float ds[4][VT];
-        auto prepare = [&](int q) {                                              // ds of quad q from window buffer q & 1 and gn
+        float ds[4][VT], s[4][VT];
+        auto resample = [&](int q) {                                             // samples of quad q from window buffer q & 1
             const int boff = (q & 1) * buf_bytes;
-            float g[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = gn[i];
-            if (q + 1 < nq) load_g(q + 1);
-            float s[4][VT];
 #pragma unroll
             for (int v = 0; v < VT; ++v) {                                       // one view at a time: 16 tap registers, not 64
                 __builtin_amdgcn_sched_barrier(0);
                 const int base = a0[v] + boff, row1 = base + ws16[v];
                 const f32x4 ta = lds_tap(smem, base), tb = lds_tap(smem, base + 16), tc = lds_tap(smem, row1), td = lds_tap(smem, row1 + 16);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s[i][v] = bilerp(ta.v[i], tb.v[i], tc.v[i], td.v[i], w00[v], w01[v], w10[v], w11[v]);
+                for (int i = 0; i < 4; ++i) {
+                    s[i][v] = bilerp(ta.v[i], tb.v[i], tc.v[i], td.v[i], w00[v], w01[v], w10[v], w11[v]);
+                    asm volatile("" : "+v"(s[i][v]));                              // fold here (not sunk below the adds)
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
+        };
+        auto jacobian = [&](int q) {                                             // ds of quad q from its samples and gn; max |ds| published
+            float g[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) g[i] = gn[i];
+            if (q + 1 < nq) load_g(q + 1);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 aggregate_grad<METHOD, VT>(s[i], g[i], ds[i]);
@@ -269,7 +274,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
             }
         };
         if (nq > 1) dma(1);
-        prepare(0);
+        resample(0);
+        jacobian(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // window 1 has landed
         lds_barrier();
 #pragma nounroll
@@ -279,6 +285,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
             // block-wide max |ds| (weights are <= 1) and the brick's tap multiplicity, rounded to int32, ds_add_u32.
             // 2^e > max |ds| of the channel  ->  scale = 2^(hbits - e): |ds * w * scale| < 2^hbits.  Exponent clamped to normal
             // floats; an all-zero channel adds nothing.
+            // The LDS pipe is in order: the window reads of quad q+1 go ahead of this quad's 64 adds per lane, whose
+            // service time then hides under the Jacobian of quad q+1 (VALU only).
+            if (q + 1 < nq) resample(q + 1);
             float scale[4], inv_scale[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -312,7 +321,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
             }
             __builtin_amdgcn_sched_barrier(0);
             if (q + 2 < nq) dma(q + 2);                                          // into the buffer quad q was sampled from
-            if (q + 1 < nq) prepare(q + 1);
+            if (q + 1 < nq) jacobian(q + 1);
             lds_barrier();                                                       // adds of quad q landed; max of quad q+1 published
             // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction
             float *gq = gk + (long long)q * HW * 4;
