@@ -66,7 +66,9 @@ typedef enum mvhmr_layout_t {
 typedef enum mvhmr_variant_t {
     MVHMR_VARIANT_AUTO = 0,
     MVHMR_VARIANT_GATHER = 1, /* channel-per-lane gather from L2, any shape */
-    MVHMR_VARIANT_BRICK = 2   /* voxel bricks with LDS-staged feature patches */
+    MVHMR_VARIANT_BRICK = 2   /* voxel bricks with LDS-staged feature windows (forward) and LDS-accumulated
+                                 gradient windows (backward): fp32, 2 or 4 views, C % 4 == 0, volume divisible
+                                 into 4 x 8 x 32 bricks; anything else is MVHMR_ERR_UNSUPPORTED */
 } mvhmr_variant_t;
 
 typedef struct mvhmr_unproject_desc {
@@ -107,7 +109,9 @@ int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *featur
  * (they are built from numpy / arange, aggregation.py:132-187).
  *   grad_out       (B,C,X,Y,Z) desc->out_dtype                                          [read]
  *   grad_features  same shape/layout/dtype as features, every element is written        [write]
- * Scatter-adds use fp32 float atomics, so low-order bits can differ from run to run.
+ * Scatter-adds use fp32 float atomics, so low-order bits can differ from run to run.  The brick variant sums a
+ * brick's contributions per pixel in fixed point first (one power-of-two scale per channel, resolution ~2^-25 of the
+ * channel's largest contribution in the brick) and issues one float atomic per window pixel.
  */
 int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_out, const void *features,
                              const float *proj, const float *coords, void *grad_features, void *workspace,

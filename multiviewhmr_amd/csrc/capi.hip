@@ -101,7 +101,7 @@ bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->
 
 // The brick backward (window gradients accumulated in LDS in fixed point, then flushed with 256-B shaped float atomics)
 // is the default wherever the brick forward is: ~20 GB of global atomic traffic instead of the gather backward's 137 GB
-// (profiles/r01_bwd_*).  variant = gather keeps the gather backward.
+// (17 ms against 104 ms at the north-star size: profiles/r01_final_pmc.txt).  variant = gather keeps the gather backward.
 bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
 {
     return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_supported(p);

@@ -1,21 +1,22 @@
-// "brick" variant of the backward pass (gradient w.r.t. the feature maps).  EXPERIMENTAL: correct (parity-tested) but
-// slower than the gather backward on gfx950 -- LDS float atomics run at ~116 cycles per wave instruction, so the
-// ds_add_f32 accumulation below saturates the LDS pipe (189 ms vs 104 ms at the north-star size).  Selected only by
-// variant = brick; kept as the starting point for a non-atomic (turn-taking read-add-write) accumulation.
+// "brick" variant of the backward pass (gradient w.r.t. the feature maps): the default wherever the brick forward runs.
 //
 // The gather backward scatters every tap with a global float atomic: 4 taps x 4 B per (voxel, view, channel) = 137 GB of
 // atomic traffic at the north-star size against a chip-wide rate of ~1.3 TB/s -- ~0.1 s.  Here the same bricks and
-// windows as the forward (unproject_brick.hip) are used to privatise the accumulation:
+// windows as the forward (unproject_brick.hip) are used to sum on chip first:
 //   per brick and channel quad   re-sample the brick's voxels from the LDS-staged feature window (recompute, nothing
 //                                is saved by the forward), apply the aggregate's Jacobian (aggregate_grad), and add
-//                                ds * w into a GRADIENT window in LDS with ds_add_f32 (planar per channel, so that a
-//                                wave's lanes -- different window rows -- spread over the banks);
+//                                ds * w into a GRADIENT window in LDS (planar per channel, so that a wave's lanes --
+//                                different window rows -- spread over the banks).  LDS float atomics run at ~190 cycles
+//                                per wave instruction on gfx950, integer ones at 4-6 (scripts/microbench_ldsatomic.hip):
+//                                the window is accumulated in FIXED POINT, one power-of-two scale per channel and quad
+//                                chosen from the block-wide max |ds| and the brick's tap multiplicity, ds_add_u32;
 //   then                         flush the gradient window: one global float atomic per window pixel and channel, issued
 //                                as 16 pixels x 4 channels = 256 contiguous bytes of the quad-planar accumulator per wave
 //                                instruction (the full-rate shape on gfx950) -- ~20 GB instead of 137 GB.
 // The accumulator is fp32 quad-planar (B,V,C/4,Hf,Wf,4), zeroed by the caller; a layout pass turns it into the caller's
-// gradient tensor.  Float atomics: run-to-run differences in the last bits (documented in the ABI).
+// gradient tensor.  Float atomics in the flush: run-to-run differences in the last bits (documented in the ABI).
 // Autograd semantics as in the gather variant / the oracle: zero-weight taps (outside the image, z <= 0) receive nothing.
+// Measured at the north-star size: 17.1 ms (gather backward: 104 ms); DESIGN.md 5.2, profiles/r01_final_pmc.txt.
 #include "brick_common.h"
 #include "kernels.h"
 
