@@ -62,7 +62,10 @@ typedef enum mvhmr_layout_t {
                                only produced by mvhmr_convert_features (C % 4 == 0) */
 } mvhmr_layout_t;
 
-/* kernel selection; AUTO picks the fastest applicable one.  The others exist for tests and profiling. */
+/* kernel selection; AUTO picks the fastest applicable one.  The others exist for tests and profiling.
+ * AUTO with planar features of a shape both variants serve decides ON THE DEVICE (cameras and voxel pitch decide whether
+ * the brick variant's LDS windows fit): both variants are launched behind a gate and one of them runs; stream-ordered, no
+ * host synchronisation.  mvhmr_unproject_selected_variant reports the variant AUTO prefers for the shape. */
 typedef enum mvhmr_variant_t {
     MVHMR_VARIANT_AUTO = 0,
     MVHMR_VARIANT_GATHER = 1, /* channel-per-lane gather from L2, any shape */

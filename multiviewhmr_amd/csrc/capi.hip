@@ -107,6 +107,26 @@ bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
     return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_supported(p);
 }
 
+// AUTO on planar input, for a shape both variants serve: the variant is chosen on the device from the geometry (gate.h).
+bool geometry_gated(const mvhmr_unproject_desc *d, const Problem &p)
+{
+    return d->variant == MVHMR_VARIANT_AUTO && d->feat_layout == MVHMR_LAYOUT_BVCHW && brick_supported(p);
+}
+constexpr size_t kGateBytes = 256;
+
+// zeroes the counter at the end of the workspace region `at`, counts the overflowing bricks, arms the gate in p
+int arm_gate(Problem &p, unsigned char *at, const float *proj, const float *coords, int cap_slots, hipStream_t s)
+{
+    int *count = reinterpret_cast<int *>(at);
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
+    if (e != hipSuccess) return fail(MVHMR_ERR_LAUNCH, "geometry gate clear: %s", hipGetErrorString(e));
+    e = launch_brick_gate(proj, coords, count, cap_slots, p, s);
+    if (e != hipSuccess) return fail(MVHMR_ERR_LAUNCH, "geometry gate: %s", hipGetErrorString(e));
+    p.gate_count = count;
+    p.gate_limit = brick_count(p) / 8;          // brick variant while at most 1/8 of the bricks would take its slow path
+    return MVHMR_OK;
+}
+
 int check_ws(void *ws, size_t have, size_t need)
 {
     if (need == 0) return MVHMR_OK;
@@ -156,6 +176,7 @@ size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc)
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
     if (desc->feat_layout != MVHMR_LAYOUT_BVCHW) return 0;
+    if (geometry_gated(desc, p)) return featT_bytes(p) + kGateBytes;   // one converted copy (either layout) + the gate counter
     return pick_variant(desc, p) == MVHMR_VARIANT_BRICK ? brick_workspace_bytes(p) : featT_bytes(p);
 }
 
@@ -163,6 +184,7 @@ size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
+    if (geometry_gated(desc, p)) return featT_bytes(p) + gradT_bytes(p) + kGateBytes;
     if (bwd_uses_brick(desc, p)) return featT_bytes(p) + gradT_bytes(p);
     size_t need = desc->feat_layout == MVHMR_LAYOUT_BVCHW ? featT_bytes(p) : 0;
     if (!grad_in_place(desc, p)) need += gradT_bytes(p);
@@ -182,6 +204,20 @@ int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *featur
     if (rc != MVHMR_OK) return rc;
     rc = check_ws(workspace, workspace_bytes, mvhmr_unproject_forward_workspace_bytes(desc));
     if (rc != MVHMR_OK) return rc;
+
+    if (geometry_gated(desc, p)) {
+        // both variants are launched; the device-side brick count lets exactly one of them (and its layout pass) run
+        unsigned char *ws = static_cast<unsigned char *>(workspace);
+        rc = arm_gate(p, ws + featT_bytes(p), proj, coords, brick_fwd_cap_slots(), s);
+        if (rc != MVHMR_OK) return rc;
+        rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
+        if (rc != MVHMR_OK) return rc;
+        rc = launched(launch_to_channels_last(features, ws, p, s), "layout pass");
+        if (rc != MVHMR_OK) return rc;
+        rc = launched(launch_fwd_brick(ws, proj, coords, out, p, s), "brick forward");
+        if (rc != MVHMR_OK) return rc;
+        return launched(launch_fwd_gather(ws, proj, coords, out, p, s), "gather forward");
+    }
 
     if (variant == MVHMR_VARIANT_BRICK) {
         const void *featK = features;
@@ -218,6 +254,24 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     if (desc->variant == MVHMR_VARIANT_BRICK && !bwd_uses_brick(desc, p))
         return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype / layout");
+    if (geometry_gated(desc, p)) {
+        float *acc = reinterpret_cast<float *>(ws + featT_bytes(p));              // quad-planar or channels-last accumulator
+        rc = arm_gate(p, ws + featT_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_cap_slots(), s);
+        if (rc != MVHMR_OK) return rc;
+        rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
+        if (rc != MVHMR_OK) return rc;
+        rc = launched(launch_to_channels_last(features, ws, p, s), "layout pass");
+        if (rc != MVHMR_OK) return rc;
+        hipError_t e = hipMemsetAsync(acc, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
+        if (e != hipSuccess) return launched(e, "gradient clear");
+        rc = launched(launch_bwd_brick(ws, grad_out, proj, coords, acc, p, s), "brick backward");
+        if (rc != MVHMR_OK) return rc;
+        rc = launched(launch_bwd_gather(grad_out, ws, proj, coords, acc, p, s), "gather backward");
+        if (rc != MVHMR_OK) return rc;
+        rc = launched(launch_quad_grad_to_planar(acc, grad_features, p, s), "gradient layout pass");
+        if (rc != MVHMR_OK) return rc;
+        return launched(launch_grad_to_planar(acc, grad_features, p, s), "gradient layout pass");
+    }
     if (bwd_uses_brick(desc, p)) {
         float *gradK = reinterpret_cast<float *>(ws + featT_bytes(p));
         rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");

@@ -13,8 +13,18 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include "gate.h"
 
 namespace mvhmr {
+
+// Geometry gate (kernels.h): true when this launch is the variant the device-side brick count did NOT select.
+__device__ __forceinline__ bool gated_off(const Gate &g)
+{
+    if (!g.count) return false;
+    const bool brick = __builtin_nontemporal_load(g.count) <= g.limit;
+    return brick != (g.wants_brick != 0);
+}
+
 
 enum : int { AGG_SOFTMAX = 0, AGG_SUM = 1, AGG_MEAN = 2, AGG_MAX = 3 };
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 #include <stdint.h>
+#include "gate.h"
 
 namespace mvhmr {
 
@@ -13,7 +14,15 @@ struct Problem {
     int C4;                   // channels rounded up to a multiple of 4 (channels-last row length)
     int method;               // AGG_*
     int feat_f16, out_f16;    // storage types
+    // Geometry gate (AUTO on planar input, shapes both variants serve): `gate_count` points at a device counter of
+    // bricks whose windows overflow LDS (k_brick_gate); a gated kernel runs when (count <= gate_limit) == wants_brick
+    // and returns at once otherwise.  Null = no gate.
+    const int *gate_count = nullptr;
+    int gate_limit = 0;
 };
+
+inline Gate make_gate(const Problem &p, bool wants_brick) { return Gate{p.gate_count, p.gate_limit, wants_brick ? 1 : 0}; }
+
 
 // Raises a kernel's dynamic-LDS limit once (per kernel, per process, remembering the largest size asked for): the
 // attribute call is not a stream operation, so it is kept off the per-launch path and out of graph captures after
@@ -39,6 +48,13 @@ size_t brick_workspace_bytes(const Problem &p);
 hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, hipStream_t s);
 hipError_t launch_fwd_brick(const void *featK, const float *proj, const float *coords, void *out, const Problem &p,
                             hipStream_t s);
+
+// Counts the bricks whose pooled tap windows would not fit `cap_slots` 16-B LDS slots (from the projections of each
+// brick's 8 corner voxels; speed heuristic only) into *count (zeroed by the caller).
+hipError_t launch_brick_gate(const float *proj, const float *coords, int *count, int cap_slots, const Problem &p, hipStream_t s);
+int brick_count(const Problem &p);
+int brick_fwd_cap_slots();
+int brick_bwd_cap_slots();
 
 // brick backward: featK quad-planar features, gradK zeroed fp32 quad-planar accumulator (same shape)
 hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK,

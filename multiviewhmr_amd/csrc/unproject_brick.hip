@@ -33,8 +33,9 @@ namespace mvhmr {
 
 // features (BV, C, HW) fp32 -> (BV, C/4, HW, 4)
 __global__ void __launch_bounds__(256)
-k_to_quad_planar(const float *__restrict__ src, float4 *__restrict__ dst, int C, int HW)
+k_to_quad_planar(const float *__restrict__ src, float4 *__restrict__ dst, int C, int HW, Gate gate)
 {
+    if (gated_off(gate)) return;
     const long long bv = blockIdx.z;
     const int q = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -49,8 +50,9 @@ template <int METHOD, int VT, int NT>
 __global__ void __launch_bounds__(NT)
 k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, const float *__restrict__ coords,
             float *__restrict__ out, int C, int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample,
-            int lds_slots, int total_blocks)
+            int lds_slots, int total_blocks, Gate gate)
 {
+    if (gated_off(gate)) return;
     constexpr int BY = NT / 128, NW = NT / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_slots * 16);
@@ -353,7 +355,7 @@ hipError_t launch_v(const float4 *featK, const float *proj, const float *coords,
     if (e != hipSuccess) return e;
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
     const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;   // tile work items x 8 XCDs x samples
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, make_gate(p, true));
     return hipGetLastError();
 }
 
@@ -367,6 +369,59 @@ hipError_t launch_m(const float4 *featK, const float *proj, const float *coords,
     return hipErrorNotSupported;
 }
 }  // namespace
+
+// ---- geometry gate: one thread per brick projects the brick's 8 corner voxels into every view and sizes the pooled
+// windows the brick kernels would need (same arithmetic as their prologue: bbox + 2, odd row stride, 64-slot chunks).
+// Voxel centres are affine in the index for every volume the caller builds, so the corners bound the brick's taps.
+__global__ void __launch_bounds__(256)
+k_brick_gate(const float *__restrict__ proj, const float *__restrict__ coords, int *__restrict__ count, int V, int H, int W, int X,
+             int Y, int Z, int by, int nbx, int nby, int nbz, int total, int cap_slots, int max_chunks)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int bps = nbx * nby * nbz;
+    const int b = i / bps, r = i % bps;
+    const int kz = r % nbz, ky = (r / nbz) % nby, kx = r / (nbz * nby);
+    const long long N = (long long)X * Y * Z;
+    int used = 0, chunks_all = 0, max_stride = 0;
+    for (int v = 0; v < V; ++v) {
+        const float *P = proj + ((long long)b * V + v) * 12;
+        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+        bool front = true;
+        for (int c = 0; c < 8; ++c) {
+            const int vx = kx * kBX + ((c & 1) ? kBX - 1 : 0), vy = ky * by + ((c & 2) ? by - 1 : 0), vz = kz * kBZ + ((c & 4) ? kBZ - 1 : 0);
+            const float *Xp = coords + ((long long)b * N + ((long long)vx * Y + vy) * Z + vz) * 3;
+            const float a = P[0] * Xp[0] + P[1] * Xp[1] + P[2] * Xp[2] + P[3];
+            const float bb = P[4] * Xp[0] + P[5] * Xp[1] + P[6] * Xp[2] + P[7];
+            const float z = P[8] * Xp[0] + P[9] * Xp[1] + P[10] * Xp[2] + P[11];
+            if (!(z > 0.f)) { front = false; continue; }
+            const float ix = (a / z) / (float)H * (float)(W - 1), iy = (bb / z) / (float)W * (float)(H - 1);   // quirk Q1 as in make_taps
+            xmin = fminf(xmin, ix); xmax = fmaxf(xmax, ix); ymin = fminf(ymin, iy); ymax = fmaxf(ymax, iy);
+        }
+        if (!front || xmax < xmin) continue;                                     // behind a camera: the kernels decide per block
+        const float x0 = fmaxf(floorf(xmin), -1.f), x1 = fminf(floorf(xmax), (float)(W - 1));
+        const float y0 = fmaxf(floorf(ymin), -1.f), y1 = fminf(floorf(ymax), (float)(H - 1));
+        if (x1 < x0 || y1 < y0) continue;                                        // wholly outside the image
+        const int bw = (int)(x1 - x0) + 2, bh = (int)(y1 - y0) + 2;
+        const int stride = bw | 1, chunks = (stride * bh + 63) >> 6;
+        used += chunks << 6;
+        chunks_all += chunks;
+        max_stride = stride > max_stride ? stride : max_stride;
+    }
+    const bool fits = used <= cap_slots && chunks_all <= max_chunks && max_stride + 2 <= kZeroSlots;
+    if (!fits) atomicAdd(count, 1);
+}
+
+int brick_count(const Problem &p) { return (p.X / kBX) * (p.Y / kBYv) * (p.Z / kBZ) * p.B; }
+int brick_fwd_cap_slots() { return ((pick_lds_slots() - 2 * kZeroSlots) / 2) & ~63; }   // the 2-deep ring still stages through LDS
+
+hipError_t launch_brick_gate(const float *proj, const float *coords, int *count, int cap_slots, const Problem &p, hipStream_t s)
+{
+    const int nbx = p.X / kBX, nby = p.Y / kBYv, nbz = p.Z / kBZ, total = nbx * nby * nbz * p.B;
+    hipLaunchKernelGGL(k_brick_gate, dim3((total + 255) / 256), dim3(256), 0, s, proj, coords, count, p.V, p.H, p.W, p.X, p.Y, p.Z, kBYv,
+                       nbx, nby, nbz, total, cap_slots, kMaxChunks * (kNT / 64));
+    return hipGetLastError();
+}
 
 bool brick_supported(const Problem &p)
 {
@@ -389,7 +444,7 @@ hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, h
     if (p.feat_f16 || p.C % 4) return hipErrorNotSupported;
     const int HW = p.H * p.W;
     hipLaunchKernelGGL(k_to_quad_planar, dim3((HW + 255) / 256, p.C / 4, p.B * p.V), dim3(256), 0, s, (const float *)src,
-                       (float4 *)dst, p.C, HW);
+                       (float4 *)dst, p.C, HW, make_gate(p, true));
     return hipGetLastError();
 }
 

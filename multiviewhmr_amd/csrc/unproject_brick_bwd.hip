@@ -77,8 +77,9 @@ template <int METHOD, int VT, int NT>
 __global__ void __launch_bounds__(NT)
 k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out, const float *__restrict__ proj,
             const float *__restrict__ coords, float *__restrict__ gradK, int C, int H, int W, int X, int Y, int Z, int nby,
-            int nbz, int bricks_per_sample, int lds_bytes, int total_blocks)
+            int nbz, int bricks_per_sample, int lds_bytes, int total_blocks, Gate gate)
 {
+    if (gated_off(gate)) return;
     constexpr int BY = NT / 128, NW = NT / 64;
     extern __shared__ __align__(16) unsigned char smem[];
     BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_bytes);
@@ -359,8 +360,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
 
 // fp32 quad-planar accumulator (BV, C/4, HW, 4) -> planar gradient (BV, C, HW)
 __global__ void __launch_bounds__(256)
-k_quad_planar_to_planar(const float4 *__restrict__ src, float *__restrict__ dst, int C, int HW)
+k_quad_planar_to_planar(const float4 *__restrict__ src, float *__restrict__ dst, int C, int HW, Gate gate)
 {
+    if (gated_off(gate)) return;
     const long long bv = blockIdx.z;
     const int q = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -387,7 +389,7 @@ hipError_t launch_bv(const float4 *featK, const float *grad_out, const float *pr
     if (e != hipSuccess) return e;
     const int grid = ((bps + 7) / 8) * 8 * p.B;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kNTb), lds, s, featK, grad_out, proj, coords, gradK, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps,
-                       lds_bytes, total);
+                       lds_bytes, total, make_gate(p, true));
     return hipGetLastError();
 }
 
@@ -423,8 +425,10 @@ hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Probl
 {
     if (p.feat_f16 || p.C % 4) return hipErrorNotSupported;
     const int HW = p.H * p.W;
-    hipLaunchKernelGGL(k_quad_planar_to_planar, dim3((HW + 255) / 256, p.C / 4, p.B * p.V), dim3(256), 0, s, (const float4 *)gradK, (float *)dst, p.C, HW);
+    hipLaunchKernelGGL(k_quad_planar_to_planar, dim3((HW + 255) / 256, p.C / 4, p.B * p.V), dim3(256), 0, s, (const float4 *)gradK, (float *)dst, p.C, HW, make_gate(p, true));
     return hipGetLastError();
 }
+
+int brick_bwd_cap_slots() { return ((kBwdLdsBytes - 2 * kZeroBytes - 16 * kZeroSlots) / 48) & ~63; }
 
 }  // namespace mvhmr

@@ -19,6 +19,7 @@ namespace mvhmr {
 constexpr int kTileVox = 32;          // voxels per block: 128-B output runs; keeps the LDS tile at 33 KB (3 blocks per CU)
 constexpr int kGroupQuads = 64;      // 64 lanes x 4 channels
 constexpr int kGroupCh = 256;
+constexpr unsigned kGatedTiles = 256; // grid.x of a geometry-gated launch (each block then loops over tiles)
 
 struct alignas(16) TapRec {
     int o00, o01, o10, o11;          // element offsets (pixel * C4) inside one (b,v) channels-last map
@@ -65,15 +66,18 @@ __device__ __forceinline__ UTap uniform_rec(const TapRec &r)
 template <typename TF, typename TO, int METHOD, int VT>
 __global__ void __launch_bounds__(256)
 k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const float *__restrict__ coords,
-             TO *__restrict__ out, int Vrt, int C, int C4, int H, int W, long long N, int tstride)
+             TO *__restrict__ out, int Vrt, int C, int C4, int H, int W, long long N, int tstride, Gate gate)
 {
+    if (gated_off(gate)) return;
     const int V = VT > 0 ? VT : Vrt;
     extern __shared__ __align__(16) unsigned char smem[];
     TapRec *recs = reinterpret_cast<TapRec *>(smem);
     f32x4 *tile = reinterpret_cast<f32x4 *>(smem + sizeof(TapRec) * kTileVox * V);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, cg = blockIdx.z;
-    const long long n0 = (long long)blockIdx.x * kTileVox;
+    // one tile per iteration; the grid covers every tile (one iteration) unless the launch is geometry-gated, where a
+    // short grid keeps the cost of a gated-off launch at a few thousand empty blocks
+    for (long long n0 = (long long)blockIdx.x * kTileVox; n0 < N; n0 += (long long)gridDim.x * kTileVox) {
     const long long mapsz = (long long)H * W * C4;
     const int Q = C4 >> 2;
 
@@ -136,6 +140,8 @@ k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const
             }
         }
     }
+    __syncthreads();                                          // records and tile are rebuilt by the next iteration
+    }
 }
 
 // ------------------------------------------------------------------------------------------ backward
@@ -145,15 +151,16 @@ template <typename TF, typename TO, int METHOD, int VT>
 __global__ void __launch_bounds__(256)
 k_bwd_gather(const TO *__restrict__ grad_out, const TF *__restrict__ featT, const float *__restrict__ proj,
              const float *__restrict__ coords, float *__restrict__ gradT, int Vrt, int C, int C4, int H, int W,
-             long long N)
+             long long N, Gate gate)
 {
+    if (gated_off(gate)) return;
     const int V = VT > 0 ? VT : Vrt;
     extern __shared__ __align__(16) unsigned char smem[];
     TapRec *recs = reinterpret_cast<TapRec *>(smem);
     float *gtile = reinterpret_cast<float *>(smem + sizeof(TapRec) * kTileVox * V);   // [256 ch][kTileVox + 1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y, cg = blockIdx.z;
-    const long long n0 = (long long)blockIdx.x * kTileVox;
+    for (long long n0 = (long long)blockIdx.x * kTileVox; n0 < N; n0 += (long long)gridDim.x * kTileVox) {   // see k_fwd_gather
     const long long mapsz = (long long)H * W * C4;
 
     build_records(recs, proj, coords, b, V, n0, N, H, W, C4);
@@ -254,14 +261,17 @@ k_bwd_gather(const TO *__restrict__ grad_out, const TF *__restrict__ featT, cons
             }
         }
     }
+    __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------------------------------ layout passes
 // (BV, C, HW) -> (BV, HW, C4): 64 x 64 tiles turned through LDS, both sides coalesced.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_to_channels_last(const T *__restrict__ src, T *__restrict__ dst, int C, int C4, int HW)
+k_to_channels_last(const T *__restrict__ src, T *__restrict__ dst, int C, int C4, int HW, Gate gate)
 {
+    if (gated_off(gate)) return;
     __shared__ T t[64][65];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long bv = blockIdx.z;
@@ -280,8 +290,9 @@ k_to_channels_last(const T *__restrict__ src, T *__restrict__ dst, int C, int C4
 // fp32 channels-last gradient accumulator (BV, HW, C4) -> (BV, C, HW) in the feature dtype
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_grad_to_planar(const float *__restrict__ srcT, T *__restrict__ dst, int C, int C4, int HW)
+k_grad_to_planar(const float *__restrict__ srcT, T *__restrict__ dst, int C, int C4, int HW, Gate gate)
 {
+    if (gated_off(gate)) return;
     __shared__ float t[64][65];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const long long bv = blockIdx.z;
@@ -337,11 +348,12 @@ static hipError_t fwd_dispatch_v(const TF *featT, const float *proj, const float
     int tstride = (Q < kGroupQuads ? Q : kGroupQuads) + 1;
     tstride |= 1;
     const size_t lds = sizeof(TapRec) * kTileVox * (size_t)p.V + sizeof(f32x4) * kTileVox * (size_t)tstride;
-    const dim3 grid((unsigned)((p.N + kTileVox - 1) / kTileVox), (unsigned)p.B, (unsigned)((Q + kGroupQuads - 1) / kGroupQuads));
+    const unsigned tiles = (unsigned)((p.N + kTileVox - 1) / kTileVox);
+    const dim3 grid(p.gate_count && tiles > kGatedTiles ? kGatedTiles : tiles, (unsigned)p.B, (unsigned)((Q + kGroupQuads - 1) / kGroupQuads));
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, featT, proj, coords, out, p.V, p.C, p.C4, p.H, p.W, p.N, tstride);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, featT, proj, coords, out, p.V, p.C, p.C4, p.H, p.W, p.N, tstride, make_gate(p, false));
         return hipGetLastError();
     };
     switch (p.V) {
@@ -379,11 +391,12 @@ static hipError_t bwd_dispatch_v(const TO *go_, const TF *featT, const float *pr
                                  const Problem &p, hipStream_t s)
 {
     const size_t lds = sizeof(TapRec) * kTileVox * (size_t)p.V + sizeof(float) * kGroupCh * (kTileVox + 1);
-    const dim3 grid((unsigned)((p.N + kTileVox - 1) / kTileVox), (unsigned)p.B, (unsigned)((p.C + kGroupCh - 1) / kGroupCh));
+    const unsigned tiles = (unsigned)((p.N + kTileVox - 1) / kTileVox);
+    const dim3 grid(p.gate_count && tiles > kGatedTiles ? kGatedTiles : tiles, (unsigned)p.B, (unsigned)((p.C + kGroupCh - 1) / kGroupCh));
     auto go = [&](auto kern) -> hipError_t {
         hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, go_, featT, proj, coords, gradT, p.V, p.C, p.C4, p.H, p.W, p.N);
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, go_, featT, proj, coords, gradT, p.V, p.C, p.C4, p.H, p.W, p.N, make_gate(p, false));
         return hipGetLastError();
     };
     switch (p.V) {
@@ -420,8 +433,8 @@ hipError_t launch_to_channels_last(const void *src, void *dst, const Problem &p,
 {
     const int HW = p.H * p.W;
     const dim3 grid((HW + 63) / 64, (p.C4 + 63) / 64, (unsigned)(p.B * p.V));
-    if (p.feat_f16) hipLaunchKernelGGL(k_to_channels_last<__half>, grid, dim3(256), 0, s, (const __half *)src, (__half *)dst, p.C, p.C4, HW);
-    else hipLaunchKernelGGL(k_to_channels_last<float>, grid, dim3(256), 0, s, (const float *)src, (float *)dst, p.C, p.C4, HW);
+    if (p.feat_f16) hipLaunchKernelGGL(k_to_channels_last<__half>, grid, dim3(256), 0, s, (const __half *)src, (__half *)dst, p.C, p.C4, HW, make_gate(p, false));
+    else hipLaunchKernelGGL(k_to_channels_last<float>, grid, dim3(256), 0, s, (const float *)src, (float *)dst, p.C, p.C4, HW, make_gate(p, false));
     return hipGetLastError();
 }
 
@@ -429,8 +442,8 @@ hipError_t launch_grad_to_planar(const float *srcT, void *dst, const Problem &p,
 {
     const int HW = p.H * p.W;
     const dim3 grid((HW + 63) / 64, (p.C4 + 63) / 64, (unsigned)(p.B * p.V));
-    if (p.feat_f16) hipLaunchKernelGGL(k_grad_to_planar<__half>, grid, dim3(256), 0, s, srcT, (__half *)dst, p.C, p.C4, HW);
-    else hipLaunchKernelGGL(k_grad_to_planar<float>, grid, dim3(256), 0, s, srcT, (float *)dst, p.C, p.C4, HW);
+    if (p.feat_f16) hipLaunchKernelGGL(k_grad_to_planar<__half>, grid, dim3(256), 0, s, srcT, (__half *)dst, p.C, p.C4, HW, make_gate(p, false));
+    else hipLaunchKernelGGL(k_grad_to_planar<float>, grid, dim3(256), 0, s, srcT, (float *)dst, p.C, p.C4, HW, make_gate(p, false));
     return hipGetLastError();
 }
 

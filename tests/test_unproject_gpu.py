@@ -165,6 +165,30 @@ def test_brick_backward_vs_oracle(shape, mode, gpu):
     assert float(np.abs(f.grad.cpu().numpy() - gref).max()) <= TOL * max(1.0, float(np.abs(gref).max()) / 8.0)
 
 
+def test_geometry_gate_picks_the_variant_on_the_device(gpu):
+    """AUTO launches both variants behind a device-side gate (csrc/gate.h): coarse grids whose bricks overflow the LDS
+    windows run the gather kernels, the others the brick kernels -- bit-identical to the explicit variants"""
+    for shape, expect in ((dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)), "gather"),      # every brick overflows
+                          (dict(B=2, V=4, C=8, H=48, W=48, vol=(8, 8, 32)), "brick")):        # every brick fits
+        feats, proj, coords = _ring_problem(seed=5, **shape)
+        p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+        outs = {}
+        for variant in ("auto", "brick", "gather"):
+            f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+            out = aggregation.unprojection(f, p, c, variant=variant)
+            outs[variant] = out.detach()
+        other = "brick" if expect == "gather" else "gather"
+        assert torch.equal(outs["auto"], outs[expect]), shape
+        assert not torch.equal(outs["auto"], outs[other]) or torch.equal(outs["brick"], outs["gather"])
+        # backward through the gate against the oracle
+        f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+        out = aggregation.unprojection(f, p, c)
+        go = np.random.default_rng(9).standard_normal(tuple(out.shape), dtype=np.float32)
+        out.backward(torch.from_numpy(go).to(gpu))
+        gref = cport.backward(go, feats, proj, coords, "softmax")
+        assert float(np.abs(f.grad.cpu().numpy() - gref).max()) <= TOL * max(1.0, float(np.abs(gref).max()) / 8.0)
+
+
 def test_brick_backward_keeps_per_channel_precision(gpu):
     """the fixed-point window accumulation scales every channel by its own power of two: channels of one quad that differ
     by 20 orders of magnitude (and an all-zero one) each keep fp32-like relative accuracy"""
