@@ -7,7 +7,9 @@ namespace mvhmr {
 
 constexpr int kBZ = 32;            // z extent of a brick: 128-B output runs
 constexpr int kBX = 4;
-constexpr int kMaxChunks = 5;      // 64-slot DMA chunks per wave per quad
+constexpr int kMaxChunks = 5;      // 64-slot DMA chunks per wave per quad (1024-thread bricks)
+// 512-thread bricks (8 views) have half the waves for up to twice the window slots
+constexpr int brick_chunks_per_wave(int nt) { return nt >= 1024 ? kMaxChunks : 2 * kMaxChunks; }
 constexpr int kZeroSlots = 128;    // always-zero 16-B slots at the head of every ring buffer (row stride <= 126)
 constexpr int kZeroBytes = kZeroSlots * 16;
 

@@ -104,7 +104,7 @@ bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->
 // (17 ms against 104 ms at the north-star size: profiles/r01_final_pmc.txt).  variant = gather keeps the gather backward.
 bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_supported(p);
+    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_supported(p) && p.V <= 4;
 }
 
 // AUTO on planar input, for a shape both variants serve: the variant is chosen on the device from the geometry (gate.h).
@@ -184,7 +184,7 @@ size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
-    if (geometry_gated(desc, p)) return featT_bytes(p) + gradT_bytes(p) + kGateBytes;
+    if (geometry_gated(desc, p) && bwd_uses_brick(desc, p)) return featT_bytes(p) + gradT_bytes(p) + kGateBytes;
     if (bwd_uses_brick(desc, p)) return featT_bytes(p) + gradT_bytes(p);
     size_t need = desc->feat_layout == MVHMR_LAYOUT_BVCHW ? featT_bytes(p) : 0;
     if (!grad_in_place(desc, p)) need += gradT_bytes(p);
@@ -254,7 +254,7 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     if (desc->variant == MVHMR_VARIANT_BRICK && !bwd_uses_brick(desc, p))
         return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype / layout");
-    if (geometry_gated(desc, p)) {
+    if (geometry_gated(desc, p) && bwd_uses_brick(desc, p)) {
         float *acc = reinterpret_cast<float *>(ws + featT_bytes(p));              // quad-planar or channels-last accumulator
         rc = arm_gate(p, ws + featT_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_cap_slots(), s);
         if (rc != MVHMR_OK) return rc;

@@ -54,6 +54,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
 {
     if (gated_off(gate)) return;
     constexpr int BY = NT / 128, NW = NT / 64;
+    constexpr int MC = brick_chunks_per_wave(NT);                                 // DMA chunks a wave may own per quad
     extern __shared__ __align__(16) unsigned char smem[];
     BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_slots * 16);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
@@ -138,7 +139,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     const int nb = used <= cap3 ? 3 : 2;
     const int cap = nb == 3 ? cap3 : cap2;
     const int buf_bytes = kZeroBytes + cap * 16;                               // zero region + the pooled windows
-    const bool fits = used <= cap && nch[VT] <= kMaxChunks * NW && max_stride + 2 <= kZeroSlots;
+    const bool fits = used <= cap && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots;
     float *const obase = out + (long long)b * C * N;
     const float4 *const fk = featK + (long long)b * VT * nq * HW;                  // this sample's quad planes
 
@@ -158,11 +159,11 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         }
         const unsigned voxb = vox * 4u;
         // ---- DMA chunks of this wave: chunk c covers 64 consecutive slots of one view's window
-        unsigned g_off[kMaxChunks];                                              // byte offset inside the sample's quad plane set
-        int l_dst[kMaxChunks];
+        unsigned g_off[MC];                                              // byte offset inside the sample's quad plane set
+        int l_dst[MC];
         int n_c = 0;                                                             // chunks this wave issues per quad
 #pragma unroll
-        for (int r = 0; r < kMaxChunks; ++r) {
+        for (int r = 0; r < MC; ++r) {
             const int c = wave + r * NW;
             l_dst[r] = -1;
             g_off[r] = 0;
@@ -189,7 +190,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             const float4 *src = fk + (long long)q * HW;
             const int boff = ring(q);
 #pragma unroll
-            for (int r = 0; r < kMaxChunks; ++r)
+            for (int r = 0; r < MC; ++r)
                 if (l_dst[r] >= 0) glds16(src, g_off[r], lds_base + (unsigned)uniform(l_dst[r] + boff));
         };
         // ---- channel-quad loop, software-pipelined inside every wave (ring of nb LDS buffers):
@@ -337,25 +338,27 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
 
 // ------------------------------------------------------------------------------------------ host side
 namespace {
-constexpr int kNT = 1024;                             // 1024 voxels per brick: 4 x 8 x 32
+constexpr int kNT = 1024;                             // 2 / 4 views: 1024 voxels per brick (4 x 8 x 32), 128 VGPRs per lane
+constexpr int kNT8 = 512;                             // 8 views: 512 voxels per brick (4 x 4 x 32), 256 VGPRs per lane
 constexpr int kBYv = kNT / 128;
+constexpr int brick_threads(int V) { return V == 8 ? kNT8 : kNT; }
 
 // 16-B LDS slots the ring may use: everything but BrickShared (one block per CU owns all 160 KiB)
 int pick_lds_slots() { return (160 * 1024 - 1024) / 16; }
 
-template <int METHOD, int VT>
+template <int METHOD, int VT, int NT>
 hipError_t launch_v(const float4 *featK, const float *proj, const float *coords, float *out, const Problem &p, hipStream_t s)
 {
-    const int nbx = p.X / kBX, nby = p.Y / kBYv, nbz = p.Z / kBZ;
+    const int nbx = p.X / kBX, nby = p.Y / (NT / 128), nbz = p.Z / kBZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
     const int slots = pick_lds_slots();
     const size_t lds = (size_t)slots * 16 + sizeof(BrickShared<VT>);
-    auto kern = k_fwd_brick<METHOD, VT, kNT>;
+    auto kern = k_fwd_brick<METHOD, VT, NT>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
     const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;   // tile work items x 8 XCDs x samples
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, make_gate(p, true));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, make_gate(p, true));
     return hipGetLastError();
 }
 
@@ -363,8 +366,9 @@ template <int METHOD>
 hipError_t launch_m(const float4 *featK, const float *proj, const float *coords, float *out, const Problem &p, hipStream_t s)
 {
     switch (p.V) {
-    case 2: return launch_v<METHOD, 2>(featK, proj, coords, out, p, s);
-    case 4: return launch_v<METHOD, 4>(featK, proj, coords, out, p, s);
+    case 2: return launch_v<METHOD, 2, kNT>(featK, proj, coords, out, p, s);
+    case 4: return launch_v<METHOD, 4, kNT>(featK, proj, coords, out, p, s);
+    case 8: return launch_v<METHOD, 8, kNT8>(featK, proj, coords, out, p, s);
     }
     return hipErrorNotSupported;
 }
@@ -412,22 +416,23 @@ k_brick_gate(const float *__restrict__ proj, const float *__restrict__ coords, i
     if (!fits) atomicAdd(count, 1);
 }
 
-int brick_count(const Problem &p) { return (p.X / kBX) * (p.Y / kBYv) * (p.Z / kBZ) * p.B; }
+int brick_count(const Problem &p) { return (p.X / kBX) * (p.Y / (brick_threads(p.V) / 128)) * (p.Z / kBZ) * p.B; }
 int brick_fwd_cap_slots() { return ((pick_lds_slots() - 2 * kZeroSlots) / 2) & ~63; }   // the 2-deep ring still stages through LDS
 
 hipError_t launch_brick_gate(const float *proj, const float *coords, int *count, int cap_slots, const Problem &p, hipStream_t s)
 {
-    const int nbx = p.X / kBX, nby = p.Y / kBYv, nbz = p.Z / kBZ, total = nbx * nby * nbz * p.B;
-    hipLaunchKernelGGL(k_brick_gate, dim3((total + 255) / 256), dim3(256), 0, s, proj, coords, count, p.V, p.H, p.W, p.X, p.Y, p.Z, kBYv,
-                       nbx, nby, nbz, total, cap_slots, kMaxChunks * (kNT / 64));
+    const int nt = brick_threads(p.V), by = nt / 128;
+    const int nbx = p.X / kBX, nby = p.Y / by, nbz = p.Z / kBZ, total = nbx * nby * nbz * p.B;
+    hipLaunchKernelGGL(k_brick_gate, dim3((total + 255) / 256), dim3(256), 0, s, proj, coords, count, p.V, p.H, p.W, p.X, p.Y, p.Z, by,
+                       nbx, nby, nbz, total, cap_slots, brick_chunks_per_wave(nt) * (nt / 64));
     return hipGetLastError();
 }
 
 bool brick_supported(const Problem &p)
 {
     if (p.feat_f16 || p.out_f16) return false;                            // fp32 storage only (for now)
-    if (p.V != 2 && p.V != 4) return false;                               // 8 views: does not fit 128 VGPRs yet -> gather
-    if (p.C % 4 || p.Z % kBZ || p.X % kBX || p.Y % kBYv) return false;
+    if (p.V != 2 && p.V != 4 && p.V != 8) return false;
+    if (p.C % 4 || p.Z % kBZ || p.X % kBX || p.Y % (brick_threads(p.V) / 128)) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
     if (p.N >= (1ll << 28)) return false;                                 // 32-bit byte offsets inside one quad of the output
     return true;

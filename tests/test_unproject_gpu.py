@@ -23,10 +23,11 @@ def _dev(d, key, gpu, dtype=torch.float32):
 
 
 def _brick_ok(f, c):
-    """shapes the brick variant takes: fp32, V in {2,4}, C % 4 == 0, volume divisible into 4 x 8 x 32 bricks"""
+    """shapes the brick forward takes: fp32, V in {2,4} with 4 x 8 x 32 bricks or V == 8 with 4 x 4 x 32 bricks, C % 4 == 0"""
     X, Y, Z = c.shape[1:4]
-    return (f.dtype == torch.float32 and f.shape[1] in (2, 4) and f.shape[2] % 4 == 0
-            and X % 4 == 0 and Y % 8 == 0 and Z % 32 == 0)
+    V = f.shape[1]
+    return (f.dtype == torch.float32 and V in (2, 4, 8) and f.shape[2] % 4 == 0
+            and X % 4 == 0 and Y % (4 if V == 8 else 8) == 0 and Z % 32 == 0)
 
 
 def _scale(ref):
@@ -132,6 +133,8 @@ def test_forward_and_backward_vs_oracle(shape, mode, gpu):
     dict(B=1, V=2, C=12, H=32, W=32, vol=(4, 8, 32)),         # odd number of quads
     dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)),        # huge maps: the brick's taps overflow the LDS window -> global fallback
     dict(B=1, V=4, C=16, H=12, W=12, vol=(8, 8, 32)),         # tiny maps: most taps fall outside the image (zero padding)
+    dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views: 512-thread bricks (4 x 4 x 32), 256 VGPRs per lane
+    dict(B=1, V=8, C=8, H=32, W=32, vol=(4, 4, 64)),          # 8 views, one brick column, two z bricks
 ])
 @pytest.mark.parametrize("mode", MODES)
 def test_brick_variant_vs_oracle(shape, mode, gpu):
