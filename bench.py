@@ -210,7 +210,7 @@ def main():
 
     # Backward (gradient w.r.t. the features), reported beside the headline: SURVEY.md 8(d) quotes fwd and fwd+bwd
     # separately.  Outside the timed region of `value`; grad_out = the forward output (same shape, realistic values).
-    if rank == 0 and world == 1 and not a.no_backward and a.dtype == "f32":
+    if rank == 0 and world == 1 and not a.no_backward:
         wsb = L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc))
         ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
         gfeat = torch.empty_like(feats)

@@ -58,8 +58,8 @@ typedef enum mvhmr_layout_t {
     MVHMR_LAYOUT_BVCHW = 0, /* (B,V,C,Hf,Wf) -- the reference's contract (aggregation.py:22-23, :191) */
     MVHMR_LAYOUT_BVHWC = 1, /* (B,V,Hf,Wf,C) -- channels-last, what the gather variant reads; passing it
                                skips the layout pass (e.g. a channels_last 1x1 conv upstream) */
-    MVHMR_LAYOUT_QUAD = 2   /* (B,V,C/4,Hf,Wf,4) -- "quad-planar", what the brick variant stages into LDS;
-                               only produced by mvhmr_convert_features (C % 4 == 0) */
+    MVHMR_LAYOUT_QUAD = 2   /* (B,V,C/4,Hf,Wf,4) fp32 whatever feat_dtype -- "quad-planar", what the brick variant
+                               stages into LDS; only produced by mvhmr_convert_features (C % 4 == 0) */
 } mvhmr_layout_t;
 
 /* kernel selection; AUTO picks the fastest applicable one.  The others exist for tests and profiling.
@@ -70,7 +70,7 @@ typedef enum mvhmr_variant_t {
     MVHMR_VARIANT_AUTO = 0,
     MVHMR_VARIANT_GATHER = 1, /* channel-per-lane gather from L2, any shape */
     MVHMR_VARIANT_BRICK = 2   /* voxel bricks with LDS-staged feature windows (forward) and LDS-accumulated
-                                 gradient windows (backward): fp32, C % 4 == 0, 2 or 4 views with the volume divisible
+                                 gradient windows (backward): fp32 or fp16 storage throughout, C % 4 == 0, 2 or 4 views with the volume divisible
                                  into 4 x 8 x 32 bricks (forward and backward) or 8 views with 4 x 4 x 32 bricks
                                  (forward); anything else is MVHMR_ERR_UNSUPPORTED */
 } mvhmr_variant_t;

@@ -113,6 +113,8 @@ bool geometry_gated(const mvhmr_unproject_desc *d, const Problem &p)
     return d->variant == MVHMR_VARIANT_AUTO && d->feat_layout == MVHMR_LAYOUT_BVCHW && brick_supported(p);
 }
 constexpr size_t kGateBytes = 256;
+// the converted feature copy of a gated launch: channels-last in the feature dtype or quad-planar fp32, whichever is larger
+size_t conv_bytes(const Problem &p) { const size_t a = featT_bytes(p), b = brick_workspace_bytes(p); return a > b ? a : b; }
 
 // zeroes the counter at the end of the workspace region `at`, counts the overflowing bricks, arms the gate in p
 int arm_gate(Problem &p, unsigned char *at, const float *proj, const float *coords, int cap_slots, hipStream_t s)
@@ -176,7 +178,7 @@ size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc)
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
     if (desc->feat_layout != MVHMR_LAYOUT_BVCHW) return 0;
-    if (geometry_gated(desc, p)) return featT_bytes(p) + kGateBytes;   // one converted copy (either layout) + the gate counter
+    if (geometry_gated(desc, p)) return conv_bytes(p) + kGateBytes;   // one converted copy (either layout) + the gate counter
     return pick_variant(desc, p) == MVHMR_VARIANT_BRICK ? brick_workspace_bytes(p) : featT_bytes(p);
 }
 
@@ -184,8 +186,8 @@ size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
-    if (geometry_gated(desc, p) && bwd_uses_brick(desc, p)) return featT_bytes(p) + gradT_bytes(p) + kGateBytes;
-    if (bwd_uses_brick(desc, p)) return featT_bytes(p) + gradT_bytes(p);
+    if (geometry_gated(desc, p) && bwd_uses_brick(desc, p)) return conv_bytes(p) + gradT_bytes(p) + kGateBytes;
+    if (bwd_uses_brick(desc, p)) return brick_workspace_bytes(p) + gradT_bytes(p);
     size_t need = desc->feat_layout == MVHMR_LAYOUT_BVCHW ? featT_bytes(p) : 0;
     if (!grad_in_place(desc, p)) need += gradT_bytes(p);
     return need;
@@ -208,7 +210,7 @@ int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *featur
     if (geometry_gated(desc, p)) {
         // both variants are launched; the device-side brick count lets exactly one of them (and its layout pass) run
         unsigned char *ws = static_cast<unsigned char *>(workspace);
-        rc = arm_gate(p, ws + featT_bytes(p), proj, coords, brick_fwd_cap_slots(), s);
+        rc = arm_gate(p, ws + conv_bytes(p), proj, coords, brick_fwd_cap_slots(), s);
         if (rc != MVHMR_OK) return rc;
         rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
@@ -255,8 +257,8 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
     if (desc->variant == MVHMR_VARIANT_BRICK && !bwd_uses_brick(desc, p))
         return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype / layout");
     if (geometry_gated(desc, p) && bwd_uses_brick(desc, p)) {
-        float *acc = reinterpret_cast<float *>(ws + featT_bytes(p));              // quad-planar or channels-last accumulator
-        rc = arm_gate(p, ws + featT_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_cap_slots(), s);
+        float *acc = reinterpret_cast<float *>(ws + conv_bytes(p));               // quad-planar or channels-last accumulator
+        rc = arm_gate(p, ws + conv_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_cap_slots(), s);
         if (rc != MVHMR_OK) return rc;
         rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
@@ -273,7 +275,7 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
         return launched(launch_grad_to_planar(acc, grad_features, p, s), "gradient layout pass");
     }
     if (bwd_uses_brick(desc, p)) {
-        float *gradK = reinterpret_cast<float *>(ws + featT_bytes(p));
+        float *gradK = reinterpret_cast<float *>(ws + brick_workspace_bytes(p));
         rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
         hipError_t e = hipMemsetAsync(gradK, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
@@ -320,7 +322,7 @@ size_t mvhmr_feature_layout_bytes(const mvhmr_unproject_desc *desc, int dst_layo
     d.feat_layout = MVHMR_LAYOUT_BVCHW;
     if (check_desc(&d, &p) != MVHMR_OK) return 0;
     if (dst_layout == MVHMR_LAYOUT_BVHWC) return featT_bytes(p);
-    if (dst_layout == MVHMR_LAYOUT_QUAD && p.C4 == p.C) return featT_bytes(p);
+    if (dst_layout == MVHMR_LAYOUT_QUAD && p.C4 == p.C) return brick_workspace_bytes(p);   // always fp32, whatever the storage type
     return 0;
 }
 

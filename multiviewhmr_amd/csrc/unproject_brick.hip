@@ -31,25 +31,27 @@
 
 namespace mvhmr {
 
-// features (BV, C, HW) fp32 -> (BV, C/4, HW, 4)
+// features (BV, C, HW) fp32 or fp16 -> fp32 (BV, C/4, HW, 4): the staged copy is fp32 for either storage type (the LDS-DMA
+// moves raw bytes; fp16 features cost one widening here instead of 16 conversions per voxel, view and quad in the loop)
+template <typename TF>
 __global__ void __launch_bounds__(256)
-k_to_quad_planar(const float *__restrict__ src, float4 *__restrict__ dst, int C, int HW, Gate gate)
+k_to_quad_planar(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int HW, Gate gate)
 {
     if (gated_off(gate)) return;
     const long long bv = blockIdx.z;
     const int q = blockIdx.y;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
-    const float *s = src + (bv * C + q * 4) * HW + p;
-    dst[(bv * (C >> 2) + q) * HW + p] = make_float4(s[0], s[HW], s[2 * (long long)HW], s[3 * (long long)HW]);
+    const TF *s = src + (bv * C + q * 4) * HW + p;
+    dst[(bv * (C >> 2) + q) * HW + p] = make_float4(to_f32<TF>(s[0]), to_f32<TF>(s[HW]), to_f32<TF>(s[2 * (long long)HW]), to_f32<TF>(s[3 * (long long)HW]));
 }
 
 // NT threads, brick = 4 x (NT/128) x 32 voxels, one voxel per lane.
 // LDS: [ ring of 2 or 3 buffers | BrickShared ]; a buffer = a zero region + the views' windows, 16-B slots.
-template <int METHOD, int VT, int NT>
+template <int METHOD, int VT, int NT, typename TO>
 __global__ void __launch_bounds__(NT)
 k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, const float *__restrict__ coords,
-            float *__restrict__ out, int C, int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample,
+            TO *__restrict__ out, int C, int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample,
             int lds_slots, int total_blocks, Gate gate)
 {
     if (gated_off(gate)) return;
@@ -140,7 +142,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     const int cap = nb == 3 ? cap3 : cap2;
     const int buf_bytes = kZeroBytes + cap * 16;                               // zero region + the pooled windows
     const bool fits = used <= cap && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots;
-    float *const obase = out + (long long)b * C * N;
+    TO *const obase = out + (long long)b * C * N;
     const float4 *const fk = featK + (long long)b * VT * nq * HW;                  // this sample's quad planes
 
     if (fits) {
@@ -223,16 +225,24 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // 128-B run per channel.  (Four dword stores per quad stalled the waves at vector-memory issue: the measured 37 %.)
         // Descriptor rebuilt per quad from wave-uniform values: base = this sample's quad q; per-lane byte offset =
         // channel (lane & 3) * N * 4 + first voxel of the lane quad * 4.
-        const unsigned chan_bytes = (unsigned)(N * 4);
-        const unsigned vox_quad = (unsigned)__builtin_amdgcn_update_dpp(0, (int)voxb, 0x00, 0xF, 0xF, false);   // lane 0 of the quad
+        constexpr unsigned OSZ = sizeof(TO);                                      // fp16 storage: 8 B per lane, 64-B runs per channel
+        const unsigned chan_bytes = (unsigned)(N * OSZ);
+        const unsigned vox_quad = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(vox * OSZ), 0x00, 0xF, 0xF, false);   // lane 0 of the quad
         const unsigned st_off = vox_quad + (unsigned)(lane & 3) * chan_bytes;
         float res[4];
         auto store_quad = [&](__amdgpu_buffer_rsrc_t rs) {
             quad_transpose(res, lane);
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
-                             __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
-            __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, 18);   // nt sc1: the output must not displace the windows in L2
+            if constexpr (OSZ == 4) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
+                                 __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, 18);   // nt sc1: the output must not displace the windows in L2
+            } else {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const __half2 lo = __floats2half2_rn(res[0], res[1]), hi = __floats2half2_rn(res[2], res[3]);   // round to nearest even
+                const u32x2 d = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+                __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)st_off, 0, 18);
+            }
         };
         // one quad.  On entry both halves of quad q's taps are in flight (or landed) in T; the samples s are dead.
         // The taps of quad q+1 are requested half by half as soon as the registers of a half have been folded, so the LDS
@@ -329,9 +339,9 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]);
                 s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]);
             }
-            float *oq = obase + (long long)(q * 4) * N;
+            TO *oq = obase + (long long)(q * 4) * N;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) (oq + i * N)[vox] = aggregate<METHOD, VT>(s[i]);
+            for (int i = 0; i < 4; ++i) (oq + i * N)[vox] = from_f32<TO>(aggregate<METHOD, VT>(s[i]));
         }
     }
 }
@@ -346,14 +356,14 @@ constexpr int brick_threads(int V) { return V == 8 ? kNT8 : kNT; }
 // 16-B LDS slots the ring may use: everything but BrickShared (one block per CU owns all 160 KiB)
 int pick_lds_slots() { return (160 * 1024 - 1024) / 16; }
 
-template <int METHOD, int VT, int NT>
-hipError_t launch_v(const float4 *featK, const float *proj, const float *coords, float *out, const Problem &p, hipStream_t s)
+template <int METHOD, int VT, int NT, typename TO>
+hipError_t launch_v(const float4 *featK, const float *proj, const float *coords, TO *out, const Problem &p, hipStream_t s)
 {
     const int nbx = p.X / kBX, nby = p.Y / (NT / 128), nbz = p.Z / kBZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
     const int slots = pick_lds_slots();
     const size_t lds = (size_t)slots * 16 + sizeof(BrickShared<VT>);
-    auto kern = k_fwd_brick<METHOD, VT, NT>;
+    auto kern = k_fwd_brick<METHOD, VT, NT, TO>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
@@ -362,15 +372,29 @@ hipError_t launch_v(const float4 *featK, const float *proj, const float *coords,
     return hipGetLastError();
 }
 
-template <int METHOD>
-hipError_t launch_m(const float4 *featK, const float *proj, const float *coords, float *out, const Problem &p, hipStream_t s)
+template <int METHOD, typename TO>
+hipError_t launch_m(const float4 *featK, const float *proj, const float *coords, TO *out, const Problem &p, hipStream_t s)
 {
     switch (p.V) {
-    case 2: return launch_v<METHOD, 2, kNT>(featK, proj, coords, out, p, s);
-    case 4: return launch_v<METHOD, 4, kNT>(featK, proj, coords, out, p, s);
-    case 8: return launch_v<METHOD, 8, kNT8>(featK, proj, coords, out, p, s);
+    case 2: return launch_v<METHOD, 2, kNT, TO>(featK, proj, coords, out, p, s);
+    case 4: return launch_v<METHOD, 4, kNT, TO>(featK, proj, coords, out, p, s);
+    case 8:
+        if constexpr (sizeof(TO) == 4) return launch_v<METHOD, 8, kNT8, TO>(featK, proj, coords, out, p, s);   // fp16 store path: over 256 VGPRs
+        break;
     }
     return hipErrorNotSupported;
+}
+
+template <typename TO>
+hipError_t launch_t(const float4 *featK, const float *proj, const float *coords, TO *out, const Problem &p, hipStream_t s)
+{
+    switch (p.method) {
+    case AGG_SOFTMAX: return launch_m<AGG_SOFTMAX, TO>(featK, proj, coords, out, p, s);
+    case AGG_SUM: return launch_m<AGG_SUM, TO>(featK, proj, coords, out, p, s);
+    case AGG_MEAN: return launch_m<AGG_MEAN, TO>(featK, proj, coords, out, p, s);
+    case AGG_MAX: return launch_m<AGG_MAX, TO>(featK, proj, coords, out, p, s);
+    }
+    return hipErrorInvalidValue;
 }
 }  // namespace
 
@@ -430,8 +454,9 @@ hipError_t launch_brick_gate(const float *proj, const float *coords, int *count,
 
 bool brick_supported(const Problem &p)
 {
-    if (p.feat_f16 || p.out_f16) return false;                            // fp32 storage only (for now)
+    if (p.feat_f16 != p.out_f16) return false;                            // fp32 or fp16 storage throughout; mixed -> gather
     if (p.V != 2 && p.V != 4 && p.V != 8) return false;
+    if (p.V == 8 && p.out_f16) return false;
     if (p.C % 4 || p.Z % kBZ || p.X % kBX || p.Y % (brick_threads(p.V) / 128)) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
     if (p.N >= (1ll << 28)) return false;                                 // 32-bit byte offsets inside one quad of the output
@@ -446,10 +471,11 @@ size_t brick_workspace_bytes(const Problem &p)
 
 hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, hipStream_t s)
 {
-    if (p.feat_f16 || p.C % 4) return hipErrorNotSupported;
+    if (p.C % 4) return hipErrorNotSupported;
     const int HW = p.H * p.W;
-    hipLaunchKernelGGL(k_to_quad_planar, dim3((HW + 255) / 256, p.C / 4, p.B * p.V), dim3(256), 0, s, (const float *)src,
-                       (float4 *)dst, p.C, HW, make_gate(p, true));
+    const dim3 grid((HW + 255) / 256, p.C / 4, p.B * p.V);
+    if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, HW, make_gate(p, true));
+    else hipLaunchKernelGGL(k_to_quad_planar<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, HW, make_gate(p, true));
     return hipGetLastError();
 }
 
@@ -457,13 +483,7 @@ hipError_t launch_fwd_brick(const void *featK_, const float *proj, const float *
 {
     if (!brick_supported(p)) return hipErrorNotSupported;
     const float4 *featK = static_cast<const float4 *>(featK_);
-    switch (p.method) {
-    case AGG_SOFTMAX: return launch_m<AGG_SOFTMAX>(featK, proj, coords, (float *)out, p, s);
-    case AGG_SUM: return launch_m<AGG_SUM>(featK, proj, coords, (float *)out, p, s);
-    case AGG_MEAN: return launch_m<AGG_MEAN>(featK, proj, coords, (float *)out, p, s);
-    case AGG_MAX: return launch_m<AGG_MAX>(featK, proj, coords, (float *)out, p, s);
-    }
-    return hipErrorInvalidValue;
+    return p.out_f16 ? launch_t<__half>(featK, proj, coords, (__half *)out, p, s) : launch_t<float>(featK, proj, coords, (float *)out, p, s);
 }
 
 }  // namespace mvhmr

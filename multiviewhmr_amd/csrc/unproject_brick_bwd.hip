@@ -28,8 +28,8 @@ namespace mvhmr {
 constexpr int kBwdLdsBytes = 160 * 1024 - 1024;
 
 // Slow path of k_bwd_brick for one voxel: global float atomics per tap (bricks whose windows do not fit the LDS pool).
-template <int METHOD, int VT>
-__device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const float *gobase, float *gk, const float (*proj)[12],
+template <int METHOD, int VT, typename TO>
+__device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const TO *gobase, float *gk, const float (*proj)[12],
                                                          const float *Xp, unsigned vox, long long N, int nq, int H, int W)
 {
     const int HW = H * W;
@@ -59,7 +59,7 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float g = gobase[(long long)(q * 4 + i) * N + vox];
+            const float g = to_f32<TO>(gobase[(long long)(q * 4 + i) * N + vox]);
             float ds[VT];
             aggregate_grad<METHOD, VT>(s[i], g, ds);
 #pragma unroll
@@ -73,9 +73,9 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
     }
 }
 
-template <int METHOD, int VT, int NT>
+template <int METHOD, int VT, int NT, typename TO>
 __global__ void __launch_bounds__(NT)
-k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out, const float *__restrict__ proj,
+k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, const float *__restrict__ proj,
             const float *__restrict__ coords, float *__restrict__ gradK, int C, int H, int W, int X, int Y, int Z, int nby,
             int nbz, int bricks_per_sample, int lds_bytes, int total_blocks, Gate gate)
 {
@@ -152,7 +152,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
     const bool fits = used <= cap && nch[VT] <= kMaxChunks * NW && max_stride + 2 <= kZeroSlots;
     const float4 *const fk = featK + (long long)b * VT * nq * HW;
     float *const gk = gradK + (long long)b * VT * nq * HW * 4;
-    const float *const gobase = grad_out + (long long)b * C * N;
+    const TO *const gobase = grad_out + (long long)b * C * N;
     const unsigned chan_bytes = (unsigned)(N * 4);
     const unsigned voxb = vox * 4u;
 
@@ -207,9 +207,15 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
         // grad_out of this voxel's 4 channels (128-B runs per channel across the wave), one quad ahead
         float gn[4];
         auto load_g = [&](int q) {
-            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gobase) + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
+            if constexpr (sizeof(TO) == 4) {
+                const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<TO *>(gobase) + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) gn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)voxb, (int)(i * chan_bytes), 0));
+                for (int i = 0; i < 4; ++i) gn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)voxb, (int)(i * chan_bytes), 0));
+            } else {                                                             // fp16 storage: 64-B runs per channel
+                const TO *gp = gobase + (long long)(q * 4) * N + vox;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gn[i] = to_f32<TO>(gp[(long long)i * N]);
+            }
         };
         dma(0);
         load_g(0);
@@ -354,13 +360,14 @@ k_bwd_brick(const float4 *__restrict__ featK, const float *__restrict__ grad_out
     } else {
         // ---- windows do not fit: scatter straight to the accumulator (its own function: keeps its registers -- 16 tap
         // offsets on top of the weights -- out of the fast path's allocation, which otherwise spills in the quad loop)
-        bwd_brick_slow<METHOD, VT>(fk, gobase, gk, sh->proj, coords + ((long long)b * N + vox) * 3, vox, N, nq, H, W);
+        bwd_brick_slow<METHOD, VT, TO>(fk, gobase, gk, sh->proj, coords + ((long long)b * N + vox) * 3, vox, N, nq, H, W);
     }
 }
 
 // fp32 quad-planar accumulator (BV, C/4, HW, 4) -> planar gradient (BV, C, HW)
+template <typename TF>
 __global__ void __launch_bounds__(256)
-k_quad_planar_to_planar(const float4 *__restrict__ src, float *__restrict__ dst, int C, int HW, Gate gate)
+k_quad_planar_to_planar(const float4 *__restrict__ src, TF *__restrict__ dst, int C, int HW, Gate gate)
 {
     if (gated_off(gate)) return;
     const long long bv = blockIdx.z;
@@ -368,23 +375,23 @@ k_quad_planar_to_planar(const float4 *__restrict__ src, float *__restrict__ dst,
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= HW) return;
     const float4 g = src[(bv * (C >> 2) + q) * HW + p];
-    float *d = dst + (bv * C + q * 4) * HW + p;
-    d[0] = g.x; d[HW] = g.y; d[2 * (long long)HW] = g.z; d[3 * (long long)HW] = g.w;
+    TF *d = dst + (bv * C + q * 4) * HW + p;
+    d[0] = from_f32<TF>(g.x); d[HW] = from_f32<TF>(g.y); d[2 * (long long)HW] = from_f32<TF>(g.z); d[3 * (long long)HW] = from_f32<TF>(g.w);
 }
 
 namespace {
 constexpr int kNTb = 1024;
 constexpr int kBYb = kNTb / 128;
 
-template <int METHOD, int VT>
-hipError_t launch_bv(const float4 *featK, const float *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
+template <int METHOD, int VT, typename TO>
+hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
                      hipStream_t s)
 {
     const int nbx = p.X / kBX, nby = p.Y / kBYb, nbz = p.Z / kBZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
     const int lds_bytes = kBwdLdsBytes;
     const size_t lds = (size_t)lds_bytes + sizeof(BrickShared<VT>);
-    auto kern = k_bwd_brick<METHOD, VT, kNTb>;
+    auto kern = k_bwd_brick<METHOD, VT, kNTb, TO>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const int grid = ((bps + 7) / 8) * 8 * p.B;
@@ -393,15 +400,27 @@ hipError_t launch_bv(const float4 *featK, const float *grad_out, const float *pr
     return hipGetLastError();
 }
 
-template <int METHOD>
-hipError_t launch_bm(const float4 *featK, const float *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
+template <int METHOD, typename TO>
+hipError_t launch_bm(const float4 *featK, const TO *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
                      hipStream_t s)
 {
     switch (p.V) {
-    case 2: return launch_bv<METHOD, 2>(featK, grad_out, proj, coords, gradK, p, s);
-    case 4: return launch_bv<METHOD, 4>(featK, grad_out, proj, coords, gradK, p, s);
+    case 2: return launch_bv<METHOD, 2, TO>(featK, grad_out, proj, coords, gradK, p, s);
+    case 4: return launch_bv<METHOD, 4, TO>(featK, grad_out, proj, coords, gradK, p, s);
     }
     return hipErrorNotSupported;
+}
+
+template <typename TO>
+hipError_t launch_bt(const float4 *fk, const TO *go, const float *proj, const float *coords, float *gradK, const Problem &p, hipStream_t s)
+{
+    switch (p.method) {
+    case AGG_SOFTMAX: return launch_bm<AGG_SOFTMAX, TO>(fk, go, proj, coords, gradK, p, s);
+    case AGG_SUM: return launch_bm<AGG_SUM, TO>(fk, go, proj, coords, gradK, p, s);
+    case AGG_MEAN: return launch_bm<AGG_MEAN, TO>(fk, go, proj, coords, gradK, p, s);
+    case AGG_MAX: return launch_bm<AGG_MAX, TO>(fk, go, proj, coords, gradK, p, s);
+    }
+    return hipErrorInvalidValue;
 }
 }  // namespace
 
@@ -409,23 +428,19 @@ hipError_t launch_bm(const float4 *featK, const float *grad_out, const float *pr
 hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
                             hipStream_t s)
 {
-    if (!brick_supported(p)) return hipErrorNotSupported;
+    if (!brick_supported(p) || p.V > 4) return hipErrorNotSupported;
     const float4 *fk = static_cast<const float4 *>(featK);
-    const float *go = static_cast<const float *>(grad_out);
-    switch (p.method) {
-    case AGG_SOFTMAX: return launch_bm<AGG_SOFTMAX>(fk, go, proj, coords, gradK, p, s);
-    case AGG_SUM: return launch_bm<AGG_SUM>(fk, go, proj, coords, gradK, p, s);
-    case AGG_MEAN: return launch_bm<AGG_MEAN>(fk, go, proj, coords, gradK, p, s);
-    case AGG_MAX: return launch_bm<AGG_MAX>(fk, go, proj, coords, gradK, p, s);
-    }
-    return hipErrorInvalidValue;
+    return p.out_f16 ? launch_bt<__half>(fk, static_cast<const __half *>(grad_out), proj, coords, gradK, p, s)
+                     : launch_bt<float>(fk, static_cast<const float *>(grad_out), proj, coords, gradK, p, s);
 }
 
 hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Problem &p, hipStream_t s)
 {
-    if (p.feat_f16 || p.C % 4) return hipErrorNotSupported;
+    if (p.C % 4) return hipErrorNotSupported;
     const int HW = p.H * p.W;
-    hipLaunchKernelGGL(k_quad_planar_to_planar, dim3((HW + 255) / 256, p.C / 4, p.B * p.V), dim3(256), 0, s, (const float4 *)gradK, (float *)dst, p.C, HW, make_gate(p, true));
+    const dim3 grid((HW + 255) / 256, p.C / 4, p.B * p.V);
+    if (p.feat_f16) hipLaunchKernelGGL(k_quad_planar_to_planar<__half>, grid, dim3(256), 0, s, (const float4 *)gradK, (__half *)dst, p.C, HW, make_gate(p, true));
+    else hipLaunchKernelGGL(k_quad_planar_to_planar<float>, grid, dim3(256), 0, s, (const float4 *)gradK, (float *)dst, p.C, HW, make_gate(p, true));
     return hipGetLastError();
 }
 

@@ -254,6 +254,14 @@ def test_fp16_storage_mode(gpu):
     assert out16.dtype == torch.float16
     bound = TOL + np.abs(ref).max() * 2.0 ** -11
     assert float(np.abs(out16.float().cpu().numpy() - ref).max()) <= bound
+    for variant in ("brick", "gather"):         # both kernel families serve fp16 storage (brick: fp32 staging, fp16 stores)
+        o = aggregation.unprojection(f16, p, c, variant=variant)
+        assert o.dtype == torch.float16 and float(np.abs(o.float().cpu().numpy() - ref).max()) <= bound
+        fg = f16.clone().requires_grad_(True)
+        gg = torch.ones_like(o)
+        aggregation.unprojection(fg, p, c, variant=variant).backward(gg)
+        gr = cport.backward(gg.float().cpu().numpy(), f16.float().cpu().numpy(), proj, coords, "softmax")
+        assert float(np.abs(fg.grad.float().cpu().numpy() - gr).max()) <= TOL + np.abs(gr).max() * 2.0 ** -10
     out32 = aggregation.unprojection(f16, p, c, out_dtype=torch.float32)
     assert out32.dtype == torch.float32 and float(np.abs(out32.cpu().numpy() - ref).max()) <= TOL
     f16g = f16.clone().requires_grad_(True)
