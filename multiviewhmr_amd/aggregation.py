@@ -140,6 +140,10 @@ def unprojection(features, proj_matricies, coord_volumes, aggregation_method='so
                            % (features.device, proj_matricies.device, coord_volumes.device))
     if out_dtype is None:
         out_dtype = torch.float16 if features.dtype == torch.float16 else torch.float32
+    if features.numel() == 0 or coord_volumes.numel() == 0:
+        # empty batch / empty volume: the reference's loops do not run and its zero-initialised volume comes back
+        # (aggregation.py:25-28); nothing to launch
+        return torch.zeros((B, features.shape[2]) + tuple(coord_volumes.shape[1:4]), dtype=out_dtype, device=features.device)
     proj = proj_matricies.detach().to(torch.float32).contiguous()
     coords = coord_volumes.detach().to(torch.float32).contiguous()
     return _Unprojection.apply(features, proj, coords, _capi.AGG[aggregation_method], out_dtype, _capi.VARIANT[variant])

@@ -168,6 +168,23 @@ def test_brick_backward_vs_oracle(shape, mode, gpu):
     assert float(np.abs(f.grad.cpu().numpy() - gref).max()) <= TOL * max(1.0, float(np.abs(gref).max()) / 8.0)
 
 
+def test_empty_batch_and_non_contiguous_inputs(gpu):
+    """edge cases of the tensor contract: B = 0 returns the reference's empty zero volume; strided (non-contiguous)
+    features, projection matrices and coordinate volumes give the same result as their contiguous copies"""
+    feats, proj, coords = _ring_problem(B=2, V=4, C=8, H=24, W=24, vol=(8, 8, 32), seed=3)
+    f, p, c = torch.from_numpy(feats).to(gpu), torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    empty = aggregation.unprojection(f[:0], p[:0], c[:0])
+    assert tuple(empty.shape) == (0, 8, 8, 8, 32) and empty.dtype == torch.float32
+    ref = aggregation.unprojection(f, p, c)
+    f_nc = torch.empty(2, 4, 8, 24, 48, device=gpu)[..., ::2]
+    f_nc.copy_(f)
+    p_nc = p.transpose(2, 3).contiguous().transpose(2, 3)
+    c_nc = torch.empty(2, 8, 8, 32, 6, device=gpu)[..., ::2]
+    c_nc.copy_(c)
+    assert not f_nc.is_contiguous() and not p_nc.is_contiguous() and not c_nc.is_contiguous()
+    assert torch.equal(aggregation.unprojection(f_nc, p_nc, c_nc), ref)
+
+
 def test_geometry_gate_picks_the_variant_on_the_device(gpu):
     """AUTO launches both variants behind a device-side gate (csrc/gate.h): coarse grids whose bricks overflow the LDS
     windows run the gather kernels, the others the brick kernels -- bit-identical to the explicit variants"""
