@@ -71,8 +71,8 @@ typedef enum mvhmr_variant_t {
     MVHMR_VARIANT_GATHER = 1, /* channel-per-lane gather from L2, any shape */
     MVHMR_VARIANT_BRICK = 2   /* voxel bricks with LDS-staged feature windows (forward) and LDS-accumulated
                                  gradient windows (backward): fp32 or fp16 storage throughout, C % 4 == 0, 2 or 4 views with the volume divisible
-                                 into 4 x 8 x 32 bricks (forward and backward) or 8 views with 4 x 4 x 32 bricks
-                                 (forward); anything else is MVHMR_ERR_UNSUPPORTED */
+                                 into 4 x 8 x 32 bricks, or 8 views (fp32) with 4 x 4 x 32 bricks; anything else is
+                                 MVHMR_ERR_UNSUPPORTED */
 } mvhmr_variant_t;
 
 typedef struct mvhmr_unproject_desc {

@@ -104,7 +104,7 @@ bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->
 // (17 ms against 104 ms at the north-star size: profiles/r01_final_pmc.txt).  variant = gather keeps the gather backward.
 bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_supported(p) && p.V <= 4;
+    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_supported(p);
 }
 
 // AUTO on planar input, for a shape both variants serve: the variant is chosen on the device from the geometry (gate.h).
@@ -258,7 +258,7 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
         return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype / layout");
     if (geometry_gated(desc, p) && bwd_uses_brick(desc, p)) {
         float *acc = reinterpret_cast<float *>(ws + conv_bytes(p));               // quad-planar or channels-last accumulator
-        rc = arm_gate(p, ws + conv_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_cap_slots(), s);
+        rc = arm_gate(p, ws + conv_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_cap_slots(p), s);
         if (rc != MVHMR_OK) return rc;
         rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;

@@ -54,7 +54,7 @@ hipError_t launch_fwd_brick(const void *featK, const float *proj, const float *c
 hipError_t launch_brick_gate(const float *proj, const float *coords, int *count, int cap_slots, const Problem &p, hipStream_t s);
 int brick_count(const Problem &p);
 int brick_fwd_cap_slots();
-int brick_bwd_cap_slots();
+int brick_bwd_cap_slots(const Problem &p);
 
 // brick backward: featK quad-planar features, gradK zeroed fp32 quad-planar accumulator (same shape)
 hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK,

@@ -26,6 +26,14 @@ namespace mvhmr {
 //   feature buffer = kZeroBytes of zeros + cap 16-B slots (as in the forward)
 //   gradient plane = (kZeroSlots + cap) floats; the first kZeroSlots only ever receive +0 (samples that are identically zero)
 constexpr int kBwdLdsBytes = 160 * 1024 - 1024;
+// 1024-thread bricks (2 / 4 views) keep two feature windows in LDS (the next quad's is prefetched); the 512-thread bricks of
+// 8 views need the room for their windows (mean 3 300, max 4 600 slots at the configs[3] geometry) and keep one
+constexpr int bwd_feature_buffers(int nt) { return nt >= 1024 ? 2 : 1; }
+// slots per window set: NBUF * (kZeroBytes + 16 cap) + 4 planes * 4 B * (kZeroSlots + cap) <= kBwdLdsBytes
+constexpr int bwd_cap_slots(int nt)
+{
+    return ((kBwdLdsBytes - bwd_feature_buffers(nt) * kZeroBytes - 16 * kZeroSlots) / (16 * bwd_feature_buffers(nt) + 16)) & ~63;
+}
 
 // Slow path of k_bwd_brick for one voxel: global float atomics per tap (bricks whose windows do not fit the LDS pool).
 template <int METHOD, int VT, typename TO>
@@ -81,6 +89,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
 {
     if (gated_off(gate)) return;
     constexpr int BY = NT / 128, NW = NT / 64;
+    constexpr int MC = brick_chunks_per_wave(NT);
+    constexpr int NBUF = bwd_feature_buffers(NT);                                // feature windows in LDS: 2 (next quad prefetched) or 1
     extern __shared__ __align__(16) unsigned char smem[];
     BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_bytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
@@ -143,13 +153,13 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         used += chunks << 6;
         nch[v + 1] = nch[v] + chunks;
     }
-    // capacity: 2 * (kZeroBytes + 16 cap) + 4 * 4 * (kZeroSlots + cap) <= kLdsBytes.  Compile-time, so that the plane and
+    // capacity (bwd_cap_slots): compile-time, so that the plane and
     // buffer strides fold into the immediate offsets of the ds_ instructions (run-time strides cost 32 address registers)
-    constexpr int cap = ((kBwdLdsBytes - 2 * kZeroBytes - 16 * kZeroSlots) / 48) & ~63;
+    constexpr int cap = bwd_cap_slots(NT);
     constexpr int buf_bytes = kZeroBytes + cap * 16;
     constexpr int plane_floats = kZeroSlots + cap;
-    int *const iplanes = reinterpret_cast<int *>(smem + 2 * buf_bytes);
-    const bool fits = used <= cap && nch[VT] <= kMaxChunks * NW && max_stride + 2 <= kZeroSlots;
+    int *const iplanes = reinterpret_cast<int *>(smem + NBUF * buf_bytes);
+    const bool fits = used <= cap && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots;
     const float4 *const fk = featK + (long long)b * VT * nq * HW;
     float *const gk = gradK + (long long)b * VT * nq * HW * 4;
     const TO *const gobase = grad_out + (long long)b * C * N;
@@ -157,7 +167,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     const unsigned voxb = vox * 4u;
 
     if (fits) {
-        for (int i = tid; i < kZeroSlots * 2; i += NT)
+        for (int i = tid; i < kZeroSlots * NBUF; i += NT)
             *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int i = tid; i < 4 * plane_floats; i += NT) iplanes[i] = 0;
         if (tid < 9) sh->aux[tid] = 0;
@@ -172,10 +182,10 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             ws16[v] = ws[v] * 16;
         }
         // ---- chunks of this wave (64 consecutive window slots of one view): DMA source + flush destination
-        unsigned g_off[kMaxChunks];                                              // bit 0: the lane's slot is a real window pixel inside the image
-        int l_dst[kMaxChunks], c_slot[kMaxChunks];
+        unsigned g_off[MC];                                              // bit 0: the lane's slot is a real window pixel inside the image
+        int l_dst[MC], c_slot[MC];
 #pragma unroll
-        for (int r = 0; r < kMaxChunks; ++r) {
+        for (int r = 0; r < MC; ++r) {
             const int c = wave + r * NW;
             l_dst[r] = -1; c_slot[r] = 0; g_off[r] = 0;
             if (c < nch[VT]) {
@@ -198,9 +208,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
         auto dma = [&](int q) {
             const float4 *src = fk + (long long)q * HW;
-            const int boff = (q & 1) * buf_bytes;
+            const int boff = (q & (NBUF - 1)) * buf_bytes;
 #pragma unroll
-            for (int r = 0; r < kMaxChunks; ++r)
+            for (int r = 0; r < MC; ++r)
                 if (l_dst[r] >= 0) glds16(src, g_off[r] & ~15u, lds_base + (unsigned)uniform(l_dst[r] + boff));
         };
 
@@ -251,8 +261,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         // Requests go out BEFORE the flush: a CU's vector-memory pipe is in order and a flush's ~160 atomic instructions take
         // microseconds to drain -- loads queued behind them would stall the next quad.
         float ds[4][VT], s[4][VT];
-        auto resample = [&](int q) {                                             // samples of quad q from window buffer q & 1
-            const int boff = (q & 1) * buf_bytes;
+        auto resample = [&](int q) {                                             // samples of quad q from its window buffer
+            const int boff = (q & (NBUF - 1)) * buf_bytes;
 #pragma unroll
             for (int v = 0; v < VT; ++v) {                                       // one view at a time: 16 tap registers, not 64
                 __builtin_amdgcn_sched_barrier(0);
@@ -281,8 +291,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 if (lane == 0) atomicMax(&sh->aux[(q & 1) * 4 + i], bb);            // one scale per channel of the quad
             }
         };
-        if (nq > 1) dma(1);
+        if (NBUF == 2 && nq > 1) dma(1);
         resample(0);
+        if (NBUF == 1 && nq > 1) { lds_barrier(); dma(1); }                      // single buffer: every wave has sampled window 0
         jacobian(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // window 1 has landed
         lds_barrier();
@@ -328,7 +339,10 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
-            if (q + 2 < nq) dma(q + 2);                                          // into the buffer quad q was sampled from
+            if (q + 2 < nq) {
+                if (NBUF == 1) lds_barrier();                                    // single buffer: every wave has sampled window q+1
+                dma(q + 2);                                                      // into the buffer quad q (or q+1) was sampled from
+            }
             if (q + 1 < nq) jacobian(q + 1);
             lds_barrier();                                                       // adds of quad q landed; max of quad q+1 published
             // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction
@@ -336,7 +350,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             int n_at = 0;                                                        // atomic instructions this wave issues for this quad
             const float inv_ch = (lane & 2) ? ((lane & 1) ? inv_scale[3] : inv_scale[2]) : ((lane & 1) ? inv_scale[1] : inv_scale[0]);
 #pragma unroll
-            for (int r = 0; r < kMaxChunks; ++r) {
+            for (int r = 0; r < MC; ++r) {
                 if (l_dst[r] < 0) continue;
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
@@ -380,22 +394,22 @@ k_quad_planar_to_planar(const float4 *__restrict__ src, TF *__restrict__ dst, in
 }
 
 namespace {
-constexpr int kNTb = 1024;
-constexpr int kBYb = kNTb / 128;
+constexpr int kNTb = 1024;                            // 2 / 4 views
+constexpr int kNTb8 = 512;                            // 8 views: 4 x 4 x 32 bricks, 256 VGPRs per lane, ONE feature window in LDS
 
-template <int METHOD, int VT, typename TO>
+template <int METHOD, int VT, int NT, typename TO>
 hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
                      hipStream_t s)
 {
-    const int nbx = p.X / kBX, nby = p.Y / kBYb, nbz = p.Z / kBZ;
+    const int nbx = p.X / kBX, nby = p.Y / (NT / 128), nbz = p.Z / kBZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
     const int lds_bytes = kBwdLdsBytes;
     const size_t lds = (size_t)lds_bytes + sizeof(BrickShared<VT>);
-    auto kern = k_bwd_brick<METHOD, VT, kNTb, TO>;
+    auto kern = k_bwd_brick<METHOD, VT, NT, TO>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const int grid = ((bps + 7) / 8) * 8 * p.B;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kNTb), lds, s, featK, grad_out, proj, coords, gradK, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, grad_out, proj, coords, gradK, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps,
                        lds_bytes, total, make_gate(p, true));
     return hipGetLastError();
 }
@@ -405,8 +419,11 @@ hipError_t launch_bm(const float4 *featK, const TO *grad_out, const float *proj,
                      hipStream_t s)
 {
     switch (p.V) {
-    case 2: return launch_bv<METHOD, 2, TO>(featK, grad_out, proj, coords, gradK, p, s);
-    case 4: return launch_bv<METHOD, 4, TO>(featK, grad_out, proj, coords, gradK, p, s);
+    case 2: return launch_bv<METHOD, 2, kNTb, TO>(featK, grad_out, proj, coords, gradK, p, s);
+    case 4: return launch_bv<METHOD, 4, kNTb, TO>(featK, grad_out, proj, coords, gradK, p, s);
+    case 8:
+        if constexpr (sizeof(TO) == 4) return launch_bv<METHOD, 8, kNTb8, TO>(featK, grad_out, proj, coords, gradK, p, s);
+        break;
     }
     return hipErrorNotSupported;
 }
@@ -428,7 +445,7 @@ hipError_t launch_bt(const float4 *fk, const TO *go, const float *proj, const fl
 hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
                             hipStream_t s)
 {
-    if (!brick_supported(p) || p.V > 4) return hipErrorNotSupported;
+    if (!brick_supported(p)) return hipErrorNotSupported;
     const float4 *fk = static_cast<const float4 *>(featK);
     return p.out_f16 ? launch_bt<__half>(fk, static_cast<const __half *>(grad_out), proj, coords, gradK, p, s)
                      : launch_bt<float>(fk, static_cast<const float *>(grad_out), proj, coords, gradK, p, s);
@@ -444,6 +461,6 @@ hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Probl
     return hipGetLastError();
 }
 
-int brick_bwd_cap_slots() { return ((kBwdLdsBytes - 2 * kZeroBytes - 16 * kZeroSlots) / 48) & ~63; }
+int brick_bwd_cap_slots(const Problem &p) { return bwd_cap_slots(p.V == 8 ? kNTb8 : kNTb); }
 
 }  // namespace mvhmr

@@ -154,6 +154,8 @@ def test_brick_variant_vs_oracle(shape, mode, gpu):
     dict(B=1, V=2, C=12, H=32, W=32, vol=(4, 8, 64)),         # odd number of quads, two z bricks per column
     dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)),        # windows overflow the LDS pool: out-of-line global-atomic path
     dict(B=1, V=4, C=16, H=12, W=12, vol=(8, 8, 32)),         # tiny maps: most taps outside the image, lanes masked out of the adds
+    dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views: 512-thread bricks, one feature window in LDS
+    dict(B=1, V=8, C=8, H=32, W=32, vol=(4, 4, 64)),          # 8 views, two z bricks
 ])
 @pytest.mark.parametrize("mode", MODES)
 def test_brick_backward_vs_oracle(shape, mode, gpu):
