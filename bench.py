@@ -142,10 +142,14 @@ def main():
     desc.variant = _capi.VARIANT[a.variant]
     # planar (reference-contract) input: the step runs the layout pass, then the fused kernel on its result
     desc.feat_layout = _capi.LAYOUT_BVCHW
-    variant = L.mvhmr_unproject_selected_variant(ctypes.byref(desc))
-    assert variant > 0, L.mvhmr_last_error().decode()
     vp = ctypes.c_void_p
     stream = vp(torch.cuda.current_stream(dev).cuda_stream)
+    # Set-up (outside the timed region): ask which variant the geometry gate selects for these cameras and this voxel
+    # pitch.  The step below runs the layout pass and the kernel as two calls so that HIP events can bracket each, and
+    # explicitly converted layouts are not gated -- so the variant is fixed here, as a drop-in caller's first step would.
+    variant = L.mvhmr_unproject_query_variant(ctypes.byref(desc), vp(proj.data_ptr()), vp(coords.data_ptr()), stream)
+    assert variant > 0, L.mvhmr_last_error().decode()
+    desc.variant = variant
     # the step = layout pass (planar reference-contract input -> the layout the kernel reads) + fused kernel;
     # they are launched through separate C-ABI calls so that HIP events can bracket each of them
     lay = L.mvhmr_preferred_layout(ctypes.byref(desc))

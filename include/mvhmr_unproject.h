@@ -149,6 +149,15 @@ int mvhmr_build_coord_volumes(float *coords, const float *rot, const float *cent
 /* Which kernel AUTO would run for this problem (an mvhmr_variant_t), for logs and tests. */
 int mvhmr_unproject_selected_variant(const mvhmr_unproject_desc *desc);
 
+/*
+ * Planning query for callers that run the layout pass themselves (mvhmr_convert_features + an explicit layout, which the
+ * device-side gate does not cover): the variant (mvhmr_variant_t) the gate would select for THIS geometry, or -1 on error.
+ * SYNCHRONOUS -- allocates 4 bytes, runs the gate kernel on hip_stream and waits for it: for set-up code, never for the
+ * per-step path.  proj (B,V,3,4) and coords (B,X,Y,Z,3) as for mvhmr_unproject_forward.
+ */
+int mvhmr_unproject_query_variant(const mvhmr_unproject_desc *desc, const float *proj, const float *coords,
+                                  void *hip_stream);
+
 int mvhmr_abi_version(void);
 const char *mvhmr_status_string(int status);
 const char *mvhmr_last_error(void);

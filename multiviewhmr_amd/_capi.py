@@ -20,6 +20,7 @@ EXPORTS = (
     "mvhmr_unproject_forward_workspace_bytes", "mvhmr_unproject_backward_workspace_bytes",
     "mvhmr_unproject_forward", "mvhmr_unproject_backward", "mvhmr_build_coord_volumes",
     "mvhmr_unproject_selected_variant", "mvhmr_preferred_layout", "mvhmr_feature_layout_bytes", "mvhmr_convert_features",
+    "mvhmr_unproject_query_variant",
 )
 
 
@@ -54,6 +55,8 @@ def lib():
     L.mvhmr_unproject_backward_workspace_bytes.argtypes = [dp]
     L.mvhmr_unproject_selected_variant.restype = ctypes.c_int
     L.mvhmr_unproject_selected_variant.argtypes = [dp]
+    L.mvhmr_unproject_query_variant.restype = ctypes.c_int
+    L.mvhmr_unproject_query_variant.argtypes = [dp, vp, vp, vp]
     L.mvhmr_unproject_forward.restype = ctypes.c_int
     L.mvhmr_unproject_forward.argtypes = [dp, vp, vp, vp, vp, vp, sz, vp]
     L.mvhmr_unproject_backward.restype = ctypes.c_int

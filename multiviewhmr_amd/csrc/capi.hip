@@ -173,6 +173,26 @@ int mvhmr_unproject_selected_variant(const mvhmr_unproject_desc *desc)
     return variant_conflict(desc, p, variant) == MVHMR_OK ? variant : -1;
 }
 
+int mvhmr_unproject_query_variant(const mvhmr_unproject_desc *desc, const float *proj, const float *coords, void *hip_stream)
+{
+    Problem p;
+    if (check_desc(desc, &p) != MVHMR_OK) return -1;
+    const int variant = pick_variant(desc, p);
+    if (variant_conflict(desc, p, variant) != MVHMR_OK) return -1;
+    if (desc->variant != MVHMR_VARIANT_AUTO || !brick_supported(p)) return variant;   // nothing to decide
+    if (!proj || !coords) { fail(MVHMR_ERR_INVALID_ARGUMENT, "proj / coords must be non-null"); return -1; }
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    int *count = nullptr, host = 0;
+    if (hipMalloc(&count, sizeof(int)) != hipSuccess) { fail(MVHMR_ERR_LAUNCH, "query: allocation failed"); return -1; }
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
+    if (e == hipSuccess) e = launch_brick_gate(proj, coords, count, brick_fwd_cap_slots(), p, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, count, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(count);
+    if (e != hipSuccess) { fail(MVHMR_ERR_LAUNCH, "query: %s", hipGetErrorString(e)); return -1; }
+    return host <= brick_count(p) / 8 ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
+}
+
 size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc)
 {
     Problem p;

@@ -128,13 +128,16 @@ def test_forward_and_backward_vs_oracle(shape, mode, gpu):
 
 
 @pytest.mark.parametrize("shape", [
-    dict(B=2, V=4, C=32, H=48, W=48, vol=(8, 16, 32)),        # several bricks per sample, windows inside the maps
+    dict(B=2, V=4, C=32, H=48, W=48, vol=(8, 16, 32)),        # windows of ~4 000 slots: the 2-deep ring
+    dict(B=1, V=4, C=32, H=40, W=40, vol=(16, 16, 32)),       # windows of ~2 100 slots: the 3-deep ring, 8 bricks per sample
     dict(B=1, V=2, C=8, H=24, W=24, vol=(4, 8, 64)),          # two z bricks per column
     dict(B=1, V=2, C=12, H=32, W=32, vol=(4, 8, 32)),         # odd number of quads
     dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)),        # huge maps: the brick's taps overflow the LDS window -> global fallback
     dict(B=1, V=4, C=16, H=12, W=12, vol=(8, 8, 32)),         # tiny maps: most taps fall outside the image (zero padding)
-    dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views: 512-thread bricks (4 x 4 x 32), 256 VGPRs per lane
-    dict(B=1, V=8, C=8, H=32, W=32, vol=(4, 4, 64)),          # 8 views, one brick column, two z bricks
+    dict(B=2, V=8, C=16, H=24, W=24, vol=(8, 8, 32)),         # 8 views: 512-thread bricks (4 x 4 x 32), 256 VGPRs per lane; 2 496 slots
+    dict(B=1, V=8, C=8, H=16, W=16, vol=(4, 4, 64)),          # 8 views, one brick column, two z bricks
+    dict(B=2, V=8, C=16, H=32, W=32, vol=(16, 16, 32)),       # 8 views, 32 bricks per sample
+    dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views, windows overflow (8 000 slots): slow path
 ])
 @pytest.mark.parametrize("mode", MODES)
 def test_brick_variant_vs_oracle(shape, mode, gpu):
@@ -150,12 +153,15 @@ def test_brick_variant_vs_oracle(shape, mode, gpu):
 
 
 @pytest.mark.parametrize("shape", [
-    dict(B=2, V=4, C=8, H=48, W=48, vol=(8, 8, 32)),          # windows fit: fixed-point LDS accumulation + flush
-    dict(B=1, V=2, C=12, H=32, W=32, vol=(4, 8, 64)),         # odd number of quads, two z bricks per column
+    dict(B=2, V=4, C=8, H=24, W=24, vol=(8, 8, 32)),          # windows fit (1 800 of 3 200 slots): fixed-point LDS accumulation + flush
+    dict(B=1, V=4, C=16, H=40, W=40, vol=(16, 16, 32)),       # windows fit, 8 bricks per sample
+    dict(B=2, V=4, C=8, H=48, W=48, vol=(8, 8, 32)),          # 6 100 slots: out-of-line global-atomic path
+    dict(B=1, V=2, C=12, H=32, W=32, vol=(4, 8, 64)),         # odd number of quads, two z bricks per column (fits)
     dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)),        # windows overflow the LDS pool: out-of-line global-atomic path
     dict(B=1, V=4, C=16, H=12, W=12, vol=(8, 8, 32)),         # tiny maps: most taps outside the image, lanes masked out of the adds
-    dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views: 512-thread bricks, one feature window in LDS
-    dict(B=1, V=8, C=8, H=32, W=32, vol=(4, 4, 64)),          # 8 views, two z bricks
+    dict(B=2, V=8, C=16, H=24, W=24, vol=(8, 8, 32)),         # 8 views: 512-thread bricks, one feature window in LDS (fits: 2 500 of 4 900)
+    dict(B=1, V=8, C=8, H=16, W=16, vol=(4, 4, 64)),          # 8 views, two z bricks (fits)
+    dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views, overflow: out-of-line path
 ])
 @pytest.mark.parametrize("mode", MODES)
 def test_brick_backward_vs_oracle(shape, mode, gpu):
@@ -191,7 +197,7 @@ def test_geometry_gate_picks_the_variant_on_the_device(gpu):
     """AUTO launches both variants behind a device-side gate (csrc/gate.h): coarse grids whose bricks overflow the LDS
     windows run the gather kernels, the others the brick kernels -- bit-identical to the explicit variants"""
     for shape, expect in ((dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)), "gather"),      # every brick overflows
-                          (dict(B=2, V=4, C=8, H=48, W=48, vol=(8, 8, 32)), "brick")):        # every brick fits
+                          (dict(B=2, V=4, C=8, H=24, W=24, vol=(8, 8, 32)), "brick")):        # every brick fits
         feats, proj, coords = _ring_problem(seed=5, **shape)
         p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
         outs = {}
@@ -202,6 +208,13 @@ def test_geometry_gate_picks_the_variant_on_the_device(gpu):
         other = "brick" if expect == "gather" else "gather"
         assert torch.equal(outs["auto"], outs[expect]), shape
         assert not torch.equal(outs["auto"], outs[other]) or torch.equal(outs["brick"], outs["gather"])
+        # the synchronous planning query (for callers that run the layout pass themselves) agrees with the gate
+        L = _capi.lib()
+        desc = aggregation._make_desc(torch.from_numpy(feats).to(gpu), c, _capi.AGG["softmax"], torch.float32, _capi.LAYOUT_BVCHW,
+                                      _capi.VARIANT["auto"])
+        got = L.mvhmr_unproject_query_variant(ctypes.byref(desc), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(c.data_ptr()),
+                                              ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert got == _capi.VARIANT[expect]
         # backward through the gate against the oracle
         f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
         out = aggregation.unprojection(f, p, c)
@@ -214,7 +227,7 @@ def test_geometry_gate_picks_the_variant_on_the_device(gpu):
 def test_brick_backward_keeps_per_channel_precision(gpu):
     """the fixed-point window accumulation scales every channel by its own power of two: channels of one quad that differ
     by 20 orders of magnitude (and an all-zero one) each keep fp32-like relative accuracy"""
-    feats, proj, coords = _ring_problem(B=1, V=4, C=8, H=48, W=48, vol=(8, 8, 32), seed=77)
+    feats, proj, coords = _ring_problem(B=1, V=4, C=8, H=24, W=24, vol=(8, 8, 32), seed=77)     # windows fit: the LDS path
     f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
     p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
     out = aggregation.unprojection(f, p, c, variant="brick")
