@@ -86,7 +86,12 @@ def cuboid_coords(shape, side, center=(0.0, 0.0, 0.0), theta=0.0):
 
 
 # --------------------------------------------------------------------------- unprojection cases
+ONLY = set(a for a in os.environ.get("MVHMR_GOLDEN_ONLY", "").split(",") if a)   # regenerate only these unprojection cases
+
+
 def run_unprojection_case(name, features, proj, coords, seed, modes=MODES, grad_modes=MODES):
+    if ONLY and name not in ONLY:
+        return                      # (the shared rng has been advanced by the caller either way: cases stay reproducible)
     feats = torch.from_numpy(features)
     P = torch.from_numpy(proj)
     Cv = torch.from_numpy(coords)
@@ -171,6 +176,18 @@ def unprojection_cases():
     run_unprojection_case("tiles_v4c16", feats(2, 4, 16, 32, 32, 9), np.stack([P, P[::-1].copy()]),
                           np.stack([cuboid_coords((4, 8, 32), 2500.0, theta=0.4),
                                     cuboid_coords((4, 8, 32), 2500.0, center=(100.0, 50.0, -30.0), theta=5.1)]), 9)
+
+    # 8. / 9. shapes whose tap windows fit the brick kernels' LDS pools (24x24 and 16x16 maps over the 2.5 m cuboid), so
+    # that the LDS-staged forward and the LDS-accumulated backward are pinned by reference outputs, 4 and 8 views
+    cams = ring_cameras(4, 5000.0, 1500.0, 1145.0, 1000.0, rng, jitter=0.02)
+    P = feature_level_projections(cams, (150, 150, 850, 850), (96, 96), (24, 24))
+    run_unprojection_case("bricks_v4c8", feats(2, 4, 8, 24, 24, 12), np.stack([P, P[::-1].copy()]),
+                          np.stack([cuboid_coords((8, 8, 32), 2500.0, theta=0.0),
+                                    cuboid_coords((8, 8, 32), 2500.0, center=(60.0, -40.0, 20.0), theta=2.3)]), 12)
+    cams = ring_cameras(8, 5200.0, 1600.0, 1500.0, 2048.0, rng, jitter=0.02)
+    P = feature_level_projections(cams, (300, 300, 1750, 1750), (64, 64), (16, 16))
+    run_unprojection_case("bricks_v8c8", feats(1, 8, 8, 16, 16, 13), P[None],
+                          cuboid_coords((4, 4, 64), 2500.0, theta=0.7)[None], 13)
 
 
 # --------------------------------------------------------------------------- VolumeGenerator cases
@@ -300,5 +317,6 @@ def geometry_cases():
 
 if __name__ == "__main__":
     unprojection_cases()
-    volgen_cases()
-    geometry_cases()
+    if not ONLY:
+        volgen_cases()
+        geometry_cases()
