@@ -176,6 +176,52 @@ def test_brick_backward_vs_oracle(shape, mode, gpu):
     assert float(np.abs(f.grad.cpu().numpy() - gref).max()) <= TOL * max(1.0, float(np.abs(gref).max()) / 8.0)
 
 
+def test_random_geometries_through_the_gate(gpu):
+    """seeded sweep: random view counts, channel counts, map sizes (non-square), volume extents, cuboid sizes / offsets /
+    rotations, camera distances and focal lengths (some cameras inside the volume: voxels behind them) -- forward and
+    backward of the AUTO path (whatever the device-side gate picks) against the C oracle, all four aggregation modes"""
+    rng = np.random.default_rng(2025)
+    for case in range(14):
+        V = int(rng.choice([2, 4, 4, 8]))
+        C = int(rng.choice([4, 8, 12, 20]))
+        H, W = int(rng.integers(12, 41)), int(rng.integers(12, 41))
+        X, Y, Z = int(rng.choice([4, 8, 12])), int(rng.choice([8, 16])), int(rng.choice([32, 64]))
+        B = int(rng.integers(1, 3))
+        side = float(rng.uniform(800.0, 3000.0))
+        centre = rng.uniform(-300.0, 300.0, 3)
+        theta = float(rng.uniform(0, 2 * np.pi))
+        radius = float(rng.uniform(1200.0, 6000.0))        # < ~2000: the camera sits inside a large cuboid
+        focal = float(rng.uniform(700.0, 1800.0))
+        feats = rng.standard_normal((B, V, C, H, W), dtype=np.float32) * float(rng.choice([0.3, 1.0, 4.0]))
+        proj = np.empty((B, V, 3, 4), np.float32)
+        for b in range(B):
+            for v in range(V):
+                az = 2 * np.pi * v / V + rng.uniform(-0.2, 0.2)
+                eye = np.array([radius * np.cos(az), radius * np.sin(az), rng.uniform(500.0, 2500.0)])
+                fwd = (centre - eye) / np.linalg.norm(centre - eye)
+                right = np.cross(fwd, [0, 0, 1.0]); right /= np.linalg.norm(right)
+                R = np.stack([right, np.cross(fwd, right), fwd])
+                cam = multiview.Camera(R, -R @ eye, [[focal, 0, 512], [0, focal, 512], [0, 0, 1]])
+                cam.update_after_resize((1024, 1024), (W, H))
+                proj[b, v] = cam.projection
+        g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij"), -1).astype(np.float64)
+        pts = -side / 2 + g * (side / (np.array([X, Y, Z]) - 1))
+        ct, st = np.cos(theta), np.sin(theta)
+        pts = pts @ np.array([[ct, -st, 0], [st, ct, 0], [0, 0, 1.0]]).T + centre
+        coords = np.broadcast_to(pts.astype(np.float32), (B,) + pts.shape).copy()
+        mode = MODES[case % 4]
+        f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+        p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+        out = aggregation.unprojection(f, p, c, aggregation_method=mode)
+        ref = cport.forward(feats, proj, coords, mode)
+        tag = (case, V, C, H, W, (X, Y, Z), mode)
+        assert float(np.abs(out.detach().cpu().numpy() - ref).max()) <= TOL * _scale(ref), tag
+        go = rng.standard_normal(ref.shape, dtype=np.float32)
+        out.backward(torch.from_numpy(go).to(gpu))
+        gref = cport.backward(go, feats, proj, coords, mode)
+        assert float(np.abs(f.grad.cpu().numpy() - gref).max()) <= TOL * max(1.0, float(np.abs(gref).max()) / 8.0), tag
+
+
 def test_empty_batch_and_non_contiguous_inputs(gpu):
     """edge cases of the tensor contract: B = 0 returns the reference's empty zero volume; strided (non-contiguous)
     features, projection matrices and coordinate volumes give the same result as their contiguous copies"""
