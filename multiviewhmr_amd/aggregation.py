@@ -216,18 +216,18 @@ class VolumeGenerator(nn.Module):
         batch_size = proj_matricies_org.shape[0]
         axis = self.rotation_axis()
         rots = np.empty((batch_size, 3, 3), dtype=np.float32)
-        centers = []
         for b in range(batch_size):
             theta = np.random.uniform(0.0, 2 * np.pi) if self.training else 0.0
             rots[b] = volumetric.get_rotation_matrix(axis, theta)
-            if self.use_triangulation:
-                n_views = proj_matricies_org.shape[1]
-                images_center = (torch.tensor(images_shape) / 2).expand(n_views, 2).to(proj_matricies_org.device)
-                center = multiview.triangulate_point_from_multiple_views_linear_torch(proj_matricies_org[b], images_center)
-                centers.append(center.detach().to(torch.float32).cpu())
-            else:
-                centers.append(torch.from_numpy(np.asarray(batch['keypoints_3d'][b][6, :3])).type(torch.float))
-        return torch.from_numpy(rots), torch.stack(centers)
+        if self.use_triangulation:
+            # one batched DLT on the device, no per-sample .cpu(); stays a device tensor
+            n_views = proj_matricies_org.shape[1]
+            images_center = (torch.tensor(images_shape, dtype=torch.float32) / 2).expand(n_views, 2)
+            centers = multiview.triangulate_points_from_multiple_views_linear_batch(proj_matricies_org.detach(), images_center)
+        else:
+            centers = torch.from_numpy(np.stack([np.asarray(batch['keypoints_3d'][b][6, :3], dtype=np.float32)
+                                                 for b in range(batch_size)]))
+        return torch.from_numpy(rots), centers
 
     def coord_volumes(self, rots, centers, device):
         """(B,S,S,S,3) float32 on `device`: rot @ (grid - center) + center, built by one kernel

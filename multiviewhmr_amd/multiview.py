@@ -100,3 +100,18 @@ def triangulate_point_from_multiple_views_linear_torch(proj_matricies, points, c
     A = A * confidences.view(-1, 1, 1)
     _, _, v = torch.svd(A.reshape(-1, 4))
     return homogeneous_to_euclidean((-v[:, 3]).unsqueeze(0))[0]
+
+
+def triangulate_points_from_multiple_views_linear_batch(proj_matricies, points):
+    """The same DLT for a whole batch at once: proj_matricies (B, V, 3, 4), points (V, 2) shared by the samples -> (B, 3),
+    on proj_matricies.device with no host synchronisation.  The caller (VolumeGenerator with use_triangulation, reference
+    aggregation.py:174-177) triangulates the image centre of every sample; the reference does it sample by sample with a
+    device SVD and a .cpu() each.  One batched float64 SVD of the (B, 2V, 4) system here; the right singular vector of the
+    smallest singular value is the homogeneous point (its sign cancels in the dehomogenisation)."""
+    B, V = proj_matricies.shape[:2]
+    P = proj_matricies.to(torch.float64)
+    pts = points.to(device=P.device, dtype=torch.float64)
+    A = P[:, :, 2:3].expand(B, V, 2, 4) * pts.view(1, V, 2, 1) - P[:, :, :2]
+    _, _, vh = torch.linalg.svd(A.reshape(B, 2 * V, 4), full_matrices=False)
+    h = vh[:, 3, :]
+    return (h[:, :3] / h[:, 3:4]).to(torch.float32)

@@ -56,6 +56,27 @@ def test_projection_helper(geo):
         f(P, torch.from_numpy(pts))                          # mixed numpy / torch, multiview.py:110
 
 
+def test_batched_triangulation_matches_the_per_sample_form():
+    """VolumeGenerator(use_triangulation=True) triangulates every sample's image centre in one batched call"""
+    rng = np.random.default_rng(4)
+    P = []
+    for b in range(5):
+        Pb = []
+        for v in range(4):
+            az = 2 * np.pi * v / 4 + 0.2 * b
+            eye = np.array([4500 * np.cos(az), 4500 * np.sin(az), 1400.0 + 50 * b])
+            fwd = -eye / np.linalg.norm(eye); right = np.cross(fwd, [0, 0, 1.0]); right /= np.linalg.norm(right)
+            R = np.stack([right, np.cross(fwd, right), fwd])
+            Pb.append(multiview.Camera(R, -R @ eye, [[1100.0, 0, 190], [0, 1100.0, 200], [0, 0, 1]]).projection)
+        P.append(Pb)
+    P = torch.from_numpy(np.asarray(P, dtype=np.float32))
+    uv = torch.tensor([[192.0, 192.0]]).expand(4, 2)
+    got = multiview.triangulate_points_from_multiple_views_linear_batch(P, uv).numpy()
+    for b in range(5):
+        ref = multiview.triangulate_point_from_multiple_views_linear(P[b].numpy().astype(np.float64), uv.numpy().astype(np.float64))
+        np.testing.assert_allclose(got[b], ref, rtol=0, atol=2e-2)        # mm; float32 inputs, float64 solves
+
+
 def test_triangulation(geo):
     np.testing.assert_allclose(multiview.triangulate_point_from_multiple_views_linear(geo["tri_P"], geo["tri_uv"]),
                                geo["tri_np"], rtol=1e-9, atol=1e-9)
