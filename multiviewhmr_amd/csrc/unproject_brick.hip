@@ -7,10 +7,10 @@
 // and every feature pixel must be fetched from L2 far less often than it is sampled.
 //
 // Mapping (CDNA4, wave64).
-//   block  = one voxel brick of 4 x (NT/128 * VPL) x 32 voxels of one sample, NT threads; a lane owns VPL
-//            fixed voxels for the block's lifetime, so its tap records (LDS address, 4 weights per view)
-//            are computed ONCE (device_common.h::make_taps, reference aggregation.py:38-54) and stay in
-//            registers while the block loops over all channel quads;
+//   block  = one voxel brick of 4 x (NT/128) x 32 voxels of one sample, NT threads (1024 for 2 / 4 views, 512 for 8
+//            views: 256 VGPRs per lane); a lane owns ONE voxel for the block's lifetime, so its tap records (LDS
+//            address, 4 weights per view) are computed ONCE (device_common.h::make_taps, reference
+//            aggregation.py:38-54) and stay in registers while the block loops over all channel quads;
 //   z-long bricks: the (B,C,X,Y,Z) output is written in runs of 32 consecutive z = 128 B per (channel,
 //            column) -- measured floor for full-rate HBM writes on MI355X (64-B runs: 3.4 TB/s, 32-B: 0.7);
 //   layout = features are re-laid "quad-planar" (B,V,C/4,Hf,Wf,4) by a pre-pass, so a pixel's 4 channels
@@ -18,9 +18,12 @@
 //   window = per view, the bounding box of the brick's taps (wave shuffles + one LDS atomic per wave);
 //            the views' windows are packed back to back in one LDS pool (a brick near one camera of the
 //            ring is far from the opposite one, so the SUM of the windows is what has to fit);
-//   staging = LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write), per channel quad, double-buffered:
-//            the DMA of quad q+1 is in flight while quad q is sampled; one raw s_barrier per quad behind a
-//            counted s_waitcnt vmcnt(N) that leaves the output stores in flight;
+//   staging = LDS-DMA (global_load_lds_dwordx4: no VGPRs, no ds_write), per channel quad, into a ring of 3 buffers
+//            (2 when the windows need the room): the DMA runs three quads ahead; one bare s_barrier per quad behind
+//            a counted s_waitcnt vmcnt(1) that leaves the latest output store in flight;
+//   loop   = per view: fold the taps of quad q (bilinear FMAs) and request the same view of quad q+1 at once, so that
+//            LDS reads are queued during every phase of the iteration;
+//   storage = fp32, or fp16 features / volume with the staged copy kept fp32 (widened once by the layout pass);
 //   bricks whose windows do not fit the pool (exotic cameras, huge maps) take a slower block-uniform path
 //            that samples from global memory, so geometry can only cost speed, never correctness;
 //   zero padding = a tap outside the image has weight 0 (make_taps) and its staged pixel is clamped into
