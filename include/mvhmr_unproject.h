@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define MVHMR_ABI_VERSION 1
+#define MVHMR_ABI_VERSION 2   /* 2: MVHMR_LAYOUT_QUAD became column-major (B,V,C/4,Wf,Hf,4) */
 
 typedef enum mvhmr_status_t {
     MVHMR_OK = 0,
@@ -58,8 +58,10 @@ typedef enum mvhmr_layout_t {
     MVHMR_LAYOUT_BVCHW = 0, /* (B,V,C,Hf,Wf) -- the reference's contract (aggregation.py:22-23, :191) */
     MVHMR_LAYOUT_BVHWC = 1, /* (B,V,Hf,Wf,C) -- channels-last, what the gather variant reads; passing it
                                skips the layout pass (e.g. a channels_last 1x1 conv upstream) */
-    MVHMR_LAYOUT_QUAD = 2   /* (B,V,C/4,Hf,Wf,4) fp32 whatever feat_dtype -- "quad-planar", what the brick variant
-                               stages into LDS; only produced by mvhmr_convert_features (C % 4 == 0) */
+    MVHMR_LAYOUT_QUAD = 2   /* (B,V,C/4,Wf,Hf,4) fp32 whatever feat_dtype -- column-major "quad-planar": a pixel's 4 channels
+                               are 16 contiguous bytes and a pixel COLUMN is one contiguous run, which is what the brick
+                               forward stages into LDS (tall narrow tap windows); only produced by
+                               mvhmr_convert_features (C % 4 == 0); forward only */
 } mvhmr_layout_t;
 
 /* kernel selection; AUTO picks the fastest applicable one.  The others exist for tests and profiling.
@@ -70,9 +72,10 @@ typedef enum mvhmr_variant_t {
     MVHMR_VARIANT_AUTO = 0,
     MVHMR_VARIANT_GATHER = 1, /* channel-per-lane gather from L2, any shape */
     MVHMR_VARIANT_BRICK = 2   /* voxel bricks with LDS-staged feature windows (forward) and LDS-accumulated
-                                 gradient windows (backward): fp32 or fp16 storage throughout, C % 4 == 0, 2 or 4 views with the volume divisible
-                                 into 4 x 8 x 32 bricks, or 8 views (fp32) with 4 x 4 x 32 bricks; anything else is
-                                 MVHMR_ERR_UNSUPPORTED */
+                                 gradient windows (backward): C % 4 == 0, 2 / 4 / 8 views, volume divisible into 4 x 8 x 32
+                                 bricks (4 x 4 x 32 with 8 views; the forward doubles the bricks in x when vol_x % 8 == 0);
+                                 the backward needs one storage type throughout and has no 8-view fp16 kernel;
+                                 anything else is MVHMR_ERR_UNSUPPORTED */
 } mvhmr_variant_t;
 
 typedef struct mvhmr_unproject_desc {

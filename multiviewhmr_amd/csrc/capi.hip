@@ -15,15 +15,25 @@
 using namespace mvhmr;
 
 namespace mvhmr {
+unsigned long long dynamic_lds_cache_key(int device, const void *kernel)
+{
+    // kernel entry points are at least 256-B aligned, so the low byte of the pointer is free for the device ordinal
+    return (unsigned long long)reinterpret_cast<uintptr_t>(kernel) ^ ((unsigned long long)(unsigned)device << 56) ^ (unsigned long long)(device & 0xff);
+}
+
 hipError_t allow_dynamic_lds(const void *kernel, size_t bytes)
 {
     static std::mutex mu;
-    static std::unordered_map<const void *, size_t> granted;
+    static std::unordered_map<unsigned long long, size_t> granted;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const unsigned long long key = dynamic_lds_cache_key(dev, kernel);
     std::lock_guard<std::mutex> lock(mu);
-    auto it = granted.find(kernel);
+    auto it = granted.find(key);
     if (it != granted.end() && it->second >= bytes) return hipSuccess;
-    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e == hipSuccess) granted[kernel] = bytes;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) granted[key] = bytes;
     return e;
 }
 }  // namespace mvhmr
@@ -85,12 +95,12 @@ int pick_variant(const mvhmr_unproject_desc *d, const Problem &p)
     if (d->feat_layout == MVHMR_LAYOUT_BVHWC) return MVHMR_VARIANT_GATHER;
     if (d->feat_layout == MVHMR_LAYOUT_QUAD) return MVHMR_VARIANT_BRICK;
     if (d->variant != MVHMR_VARIANT_AUTO) return d->variant;
-    return brick_supported(p) ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
+    return brick_fwd_supported(p) ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
 }
 
 int variant_conflict(const mvhmr_unproject_desc *d, const Problem &p, int variant)
 {
-    if (variant == MVHMR_VARIANT_BRICK && !brick_supported(p)) return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype");
+    if (variant == MVHMR_VARIANT_BRICK && !brick_fwd_supported(p)) return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype");
     if (d->variant != MVHMR_VARIANT_AUTO && d->variant != variant)
         return fail(MVHMR_ERR_UNSUPPORTED, "feature layout %d cannot feed kernel variant %d", d->feat_layout, d->variant);
     return MVHMR_OK;
@@ -104,28 +114,33 @@ bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->
 // (17 ms against 104 ms at the north-star size: profiles/r01_final_pmc.txt).  variant = gather keeps the gather backward.
 bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_supported(p);
+    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_bwd_supported(p);
 }
 
 // AUTO on planar input, for a shape both variants serve: the variant is chosen on the device from the geometry (gate.h).
 bool geometry_gated(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    return d->variant == MVHMR_VARIANT_AUTO && d->feat_layout == MVHMR_LAYOUT_BVCHW && brick_supported(p);
+    return d->variant == MVHMR_VARIANT_AUTO && d->feat_layout == MVHMR_LAYOUT_BVCHW && brick_fwd_supported(p);
+}
+// the backward has its own bricks and windows, hence its own gate
+bool geometry_gated_bwd(const mvhmr_unproject_desc *d, const Problem &p)
+{
+    return d->variant == MVHMR_VARIANT_AUTO && d->feat_layout == MVHMR_LAYOUT_BVCHW && brick_bwd_supported(p);
 }
 constexpr size_t kGateBytes = 256;
 // the converted feature copy of a gated launch: channels-last in the feature dtype or quad-planar fp32, whichever is larger
 size_t conv_bytes(const Problem &p) { const size_t a = featT_bytes(p), b = brick_workspace_bytes(p); return a > b ? a : b; }
 
 // zeroes the counter at the end of the workspace region `at`, counts the overflowing bricks, arms the gate in p
-int arm_gate(Problem &p, unsigned char *at, const float *proj, const float *coords, int cap_slots, hipStream_t s)
+int arm_gate(Problem &p, unsigned char *at, const float *proj, const float *coords, const GateGeom &g, hipStream_t s)
 {
     int *count = reinterpret_cast<int *>(at);
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
     if (e != hipSuccess) return fail(MVHMR_ERR_LAUNCH, "geometry gate clear: %s", hipGetErrorString(e));
-    e = launch_brick_gate(proj, coords, count, cap_slots, p, s);
+    e = launch_brick_gate(proj, coords, count, g, p, s);
     if (e != hipSuccess) return fail(MVHMR_ERR_LAUNCH, "geometry gate: %s", hipGetErrorString(e));
     p.gate_count = count;
-    p.gate_limit = brick_count(p) / 8;          // brick variant while at most 1/8 of the bricks would take its slow path
+    p.gate_limit = brick_count(p, g) / 8;       // brick variant while at most 1/8 of the bricks would take its slow path
     return MVHMR_OK;
 }
 
@@ -179,18 +194,19 @@ int mvhmr_unproject_query_variant(const mvhmr_unproject_desc *desc, const float 
     if (check_desc(desc, &p) != MVHMR_OK) return -1;
     const int variant = pick_variant(desc, p);
     if (variant_conflict(desc, p, variant) != MVHMR_OK) return -1;
-    if (desc->variant != MVHMR_VARIANT_AUTO || !brick_supported(p)) return variant;   // nothing to decide
+    if (desc->variant != MVHMR_VARIANT_AUTO || !brick_fwd_supported(p)) return variant;   // nothing to decide
     if (!proj || !coords) { fail(MVHMR_ERR_INVALID_ARGUMENT, "proj / coords must be non-null"); return -1; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     int *count = nullptr, host = 0;
     if (hipMalloc(&count, sizeof(int)) != hipSuccess) { fail(MVHMR_ERR_LAUNCH, "query: allocation failed"); return -1; }
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
-    if (e == hipSuccess) e = launch_brick_gate(proj, coords, count, brick_fwd_cap_slots(), p, s);
+    const GateGeom g = brick_fwd_gate_geom(p);
+    if (e == hipSuccess) e = launch_brick_gate(proj, coords, count, g, p, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&host, count, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(count);
     if (e != hipSuccess) { fail(MVHMR_ERR_LAUNCH, "query: %s", hipGetErrorString(e)); return -1; }
-    return host <= brick_count(p) / 8 ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
+    return host <= brick_count(p, g) / 8 ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
 }
 
 size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc)
@@ -206,7 +222,7 @@ size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
-    if (geometry_gated(desc, p) && bwd_uses_brick(desc, p)) return conv_bytes(p) + gradT_bytes(p) + kGateBytes;
+    if (geometry_gated_bwd(desc, p) && bwd_uses_brick(desc, p)) return conv_bytes(p) + gradT_bytes(p) + kGateBytes;
     if (bwd_uses_brick(desc, p)) return brick_workspace_bytes(p) + gradT_bytes(p);
     size_t need = desc->feat_layout == MVHMR_LAYOUT_BVCHW ? featT_bytes(p) : 0;
     if (!grad_in_place(desc, p)) need += gradT_bytes(p);
@@ -230,9 +246,9 @@ int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *featur
     if (geometry_gated(desc, p)) {
         // both variants are launched; the device-side brick count lets exactly one of them (and its layout pass) run
         unsigned char *ws = static_cast<unsigned char *>(workspace);
-        rc = arm_gate(p, ws + conv_bytes(p), proj, coords, brick_fwd_cap_slots(), s);
+        rc = arm_gate(p, ws + conv_bytes(p), proj, coords, brick_fwd_gate_geom(p), s);
         if (rc != MVHMR_OK) return rc;
-        rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
+        rc = launched(launch_to_quad_planar_t(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
         rc = launched(launch_to_channels_last(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
@@ -244,7 +260,7 @@ int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *featur
     if (variant == MVHMR_VARIANT_BRICK) {
         const void *featK = features;
         if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) {
-            rc = launched(launch_to_quad_planar(features, workspace, p, s), "layout pass");
+            rc = launched(launch_to_quad_planar_t(features, workspace, p, s), "layout pass");
             if (rc != MVHMR_OK) return rc;
             featK = workspace;
         }
@@ -276,9 +292,9 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
     unsigned char *ws = static_cast<unsigned char *>(workspace);
     if (desc->variant == MVHMR_VARIANT_BRICK && !bwd_uses_brick(desc, p))
         return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype / layout");
-    if (geometry_gated(desc, p) && bwd_uses_brick(desc, p)) {
+    if (geometry_gated_bwd(desc, p) && bwd_uses_brick(desc, p)) {
         float *acc = reinterpret_cast<float *>(ws + conv_bytes(p));               // quad-planar or channels-last accumulator
-        rc = arm_gate(p, ws + conv_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_cap_slots(p), s);
+        rc = arm_gate(p, ws + conv_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_gate_geom(p), s);
         if (rc != MVHMR_OK) return rc;
         rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
@@ -357,7 +373,7 @@ int mvhmr_convert_features(const mvhmr_unproject_desc *desc, const void *feature
     if (!features || !dst) return fail(MVHMR_ERR_INVALID_ARGUMENT, "features / dst must be non-null");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     if (dst_layout == MVHMR_LAYOUT_BVHWC) return launched(launch_to_channels_last(features, dst, p, s), "layout pass");
-    if (dst_layout == MVHMR_LAYOUT_QUAD) return launched(launch_to_quad_planar(features, dst, p, s), "layout pass");
+    if (dst_layout == MVHMR_LAYOUT_QUAD) return launched(launch_to_quad_planar_t(features, dst, p, s), "layout pass");
     return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown destination layout %d", dst_layout);
 }
 

@@ -24,10 +24,12 @@ struct Problem {
 inline Gate make_gate(const Problem &p, bool wants_brick) { return Gate{p.gate_count, p.gate_limit, wants_brick ? 1 : 0}; }
 
 
-// Raises a kernel's dynamic-LDS limit once (per kernel, per process, remembering the largest size asked for): the
-// attribute call is not a stream operation, so it is kept off the per-launch path and out of graph captures after
-// the first (warm-up) launch.
+// Raises a kernel's dynamic-LDS limit once per (device, kernel), remembering the largest size asked for: the attribute call
+// is not a stream operation, so it is kept off the per-launch path and out of graph captures after the first (warm-up)
+// launch.  hipFuncSetAttribute acts on the CURRENT device's function object, hence the device in the key.
 hipError_t allow_dynamic_lds(const void *kernel, size_t bytes);
+// the cache key (exposed for the unit test of the key)
+unsigned long long dynamic_lds_cache_key(int device, const void *kernel);
 
 // (B*V, C, HW) -> (B*V, HW, C4), zero-padding channels C..C4; and the inverse for gradients
 // (fp32 channels-last accumulator -> feature dtype, planar).
@@ -42,19 +44,30 @@ hipError_t launch_fwd_gather(const void *featT, const float *proj, const float *
 hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const float *proj, const float *coords,
                              float *gradT, const Problem &p, hipStream_t s);
 
-// brick variant (LDS-staged patches); returns hipErrorNotSupported when the shape does not qualify
-bool brick_supported(const Problem &p);
+// brick variant (LDS-staged windows); launches return hipErrorNotSupported when the shape does not qualify.
+//   forward : column-major quad-planar staged copy (launch_to_quad_planar_t), 4*nvox x (NT/128) x 32 bricks
+//   backward: row-major quad-planar staged copy (launch_to_quad_planar), 4 x (NT/128) x 32 bricks
+bool brick_fwd_supported(const Problem &p);
+bool brick_bwd_supported(const Problem &p);
 size_t brick_workspace_bytes(const Problem &p);
 hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, hipStream_t s);
+hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s);
 hipError_t launch_fwd_brick(const void *featK, const float *proj, const float *coords, void *out, const Problem &p,
                             hipStream_t s);
 
-// Counts the bricks whose pooled tap windows would not fit `cap_slots` 16-B LDS slots (from the projections of each
-// brick's 8 corner voxels; speed heuristic only) into *count (zeroed by the caller).
-hipError_t launch_brick_gate(const float *proj, const float *coords, int *count, int cap_slots, const Problem &p, hipStream_t s);
-int brick_count(const Problem &p);
-int brick_fwd_cap_slots();
-int brick_bwd_cap_slots(const Problem &p);
+// Geometry gate.  Counts the bricks whose pooled tap windows would not fit (from the projections of each brick's 8 corner
+// voxels; speed heuristic only) into *count (zeroed by the caller).  GateGeom describes the bricks and windows of the kernel
+// the gate decides for.
+struct GateGeom {
+    int bx, by;          // brick extent in x and y (z is always 32)
+    int column_major;    // window lines run along y (forward) or x (backward)
+    int cap_slots;       // 16-B LDS slots one window set may use
+    int max_chunks;      // 64-slot DMA chunks a block can issue per quad
+};
+GateGeom brick_fwd_gate_geom(const Problem &p);
+GateGeom brick_bwd_gate_geom(const Problem &p);
+hipError_t launch_brick_gate(const float *proj, const float *coords, int *count, const GateGeom &g, const Problem &p, hipStream_t s);
+int brick_count(const Problem &p, const GateGeom &g);
 
 // brick backward: featK quad-planar features, gradK zeroed fp32 quad-planar accumulator (same shape)
 hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK,

@@ -445,7 +445,7 @@ hipError_t launch_bt(const float4 *fk, const TO *go, const float *proj, const fl
 hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
                             hipStream_t s)
 {
-    if (!brick_supported(p)) return hipErrorNotSupported;
+    if (!brick_bwd_supported(p)) return hipErrorNotSupported;
     const float4 *fk = static_cast<const float4 *>(featK);
     return p.out_f16 ? launch_bt<__half>(fk, static_cast<const __half *>(grad_out), proj, coords, gradK, p, s)
                      : launch_bt<float>(fk, static_cast<const float *>(grad_out), proj, coords, gradK, p, s);
@@ -461,6 +461,26 @@ hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Probl
     return hipGetLastError();
 }
 
-int brick_bwd_cap_slots(const Problem &p) { return bwd_cap_slots(p.V == 8 ? kNTb8 : kNTb); }
+bool brick_bwd_supported(const Problem &p)
+{
+    if (p.feat_f16 != p.out_f16) return false;                            // fp32 or fp16 storage throughout; mixed -> gather
+    if (p.V != 2 && p.V != 4 && p.V != 8) return false;
+    if (p.V == 8 && p.out_f16) return false;
+    const int nt = p.V == 8 ? kNTb8 : kNTb;
+    if (p.C % 4 || p.Z % kBZ || p.X % kBX || p.Y % (nt / 128)) return false;
+    if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
+    if (p.N >= (1ll << 28)) return false;
+    return true;
+}
+
+GateGeom brick_bwd_gate_geom(const Problem &p)
+{
+    const int nt = p.V == 8 ? kNTb8 : kNTb;
+    GateGeom g;
+    g.bx = kBX; g.by = nt / 128; g.column_major = 0;
+    g.cap_slots = bwd_cap_slots(nt);
+    g.max_chunks = brick_chunks_per_wave(nt) * (nt / 64);
+    return g;
+}
 
 }  // namespace mvhmr

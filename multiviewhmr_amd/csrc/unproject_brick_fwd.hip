@@ -1,0 +1,175 @@
+// Host side of the brick forward (kernel: brick_fwd_kernel.h, instantiated per aggregation method in unproject_brick_fwd_m*.hip),
+// the layout passes that build the staged fp32 copies, and the geometry gate.
+#include "brick_fwd_kernel.h"
+
+namespace mvhmr {
+
+// ------------------------------------------------------------------------------------------------- layout passes
+// features (BV, C, H, W) fp32 / fp16 -> fp32 (BV, C/4, W, H, 4): COLUMN-major quad-planar, what the brick forward stages
+// (MVHMR_LAYOUT_QUAD).  One block = 4 channels x (32 x 32) pixels turned through LDS: reads are 128-B runs along x, writes
+// 512-B runs along y.  fp16 features are widened here once instead of per tap in the kernel.
+template <typename TF>
+__global__ void __launch_bounds__(256)
+k_to_quad_planar_t(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int H, int W, Gate gate)
+{
+    if (gated_off(gate)) return;
+    __shared__ float tile[4][32][33];                                           // [c][y][x], x padded: conflict-free both ways
+    const long long bv = blockIdx.z;
+    const int q = blockIdx.y;
+    const int tiles_x = (W + 31) >> 5;
+    const int x0 = (blockIdx.x % tiles_x) << 5, y0 = (blockIdx.x / tiles_x) << 5;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                     // 8 rows per pass
+    const TF *s = src + (bv * C + q * 4) * (long long)H * W;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int y = y0 + ty + 8 * i, x = x0 + tx;
+            if (y < H && x < W) tile[c][ty + 8 * i][tx] = to_f32<TF>(s[(long long)c * H * W + (long long)y * W + x]);
+        }
+    __syncthreads();
+    float4 *d = dst + (bv * (C >> 2) + q) * (long long)H * W;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int xx = ty + 8 * i, y = y0 + tx, x = x0 + xx;                    // lanes run along y
+        if (y < H && x < W) d[(long long)x * H + y] = make_float4(tile[0][tx][xx], tile[1][tx][xx], tile[2][tx][xx], tile[3][tx][xx]);
+    }
+}
+
+// features (BV, C, HW) -> fp32 (BV, C/4, HW, 4): ROW-major quad-planar, what the brick backward stages
+template <typename TF>
+__global__ void __launch_bounds__(256)
+k_to_quad_planar(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int HW, Gate gate)
+{
+    if (gated_off(gate)) return;
+    const long long bv = blockIdx.z;
+    const int q = blockIdx.y;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= HW) return;
+    const TF *s = src + (bv * C + q * 4) * HW + p;
+    dst[(bv * (C >> 2) + q) * HW + p] = make_float4(to_f32<TF>(s[0]), to_f32<TF>(s[HW]), to_f32<TF>(s[2 * (long long)HW]), to_f32<TF>(s[3 * (long long)HW]));
+}
+
+hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s)
+{
+    if (p.C % 4) return hipErrorNotSupported;
+    const dim3 grid(((p.W + 31) / 32) * ((p.H + 31) / 32), p.C / 4, p.B * p.V);
+    if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
+    else hipLaunchKernelGGL(k_to_quad_planar_t<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
+    return hipGetLastError();
+}
+
+hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, hipStream_t s)
+{
+    if (p.C % 4) return hipErrorNotSupported;
+    const int HW = p.H * p.W;
+    const dim3 grid((HW + 255) / 256, p.C / 4, p.B * p.V);
+    if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, HW, make_gate(p, true));
+    else hipLaunchKernelGGL(k_to_quad_planar<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, HW, make_gate(p, true));
+    return hipGetLastError();
+}
+
+size_t brick_workspace_bytes(const Problem &p)
+{
+    const size_t n = (size_t)p.B * p.V * p.C * p.H * p.W * sizeof(float);
+    return (n + 255) / 256 * 256;
+}
+
+// ------------------------------------------------------------------------------------------------- brick geometry
+int fwd_lds_slots() { return (160 * 1024 - 1024) / 16; }
+static int fwd_threads(int V) { return V == 8 ? 512 : 1024; }          // 8 views: 256 VGPRs per lane
+int brick_fwd_nvox(const Problem &p) { return p.X % (2 * kBX) == 0 ? 2 : 1; }   // 8 x 8 x 32 bricks when x allows, else 4 x 8 x 32
+
+bool brick_fwd_supported(const Problem &p)
+{
+    if (p.V != 2 && p.V != 4 && p.V != 8) return false;
+    if (p.C % 4 || p.Z % kBZ || p.X % kBX || p.Y % (fwd_threads(p.V) / 128)) return false;
+    if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
+    if (p.N >= (1ll << 28)) return false;                                 // 32-bit byte offsets inside one quad of the output
+    return true;
+}
+
+GateGeom brick_fwd_gate_geom(const Problem &p)
+{
+    const int nt = fwd_threads(p.V);
+    GateGeom g;
+    g.bx = kBX * brick_fwd_nvox(p); g.by = nt / 128; g.column_major = 1;
+    g.cap_slots = fwd_cap2(fwd_lds_slots());                              // the 2-deep ring still stages through LDS
+    g.max_chunks = brick_chunks_per_wave(nt) * (nt / 64);
+    return g;
+}
+
+int brick_count(const Problem &p, const GateGeom &g) { return (p.X / g.bx) * (p.Y / g.by) * (p.Z / kBZ) * p.B; }
+
+// ---- geometry gate: one thread per brick projects the brick's 8 corner voxels into every view and sizes the pooled windows the
+// brick kernels would need (same arithmetic as their prologue: bbox + 2, odd line stride, 64-slot chunks).  Voxel centres are
+// affine in the index for every volume the caller builds, so the corners bound the brick's taps; only speed depends on it.
+__global__ void __launch_bounds__(256)
+k_brick_gate(const float *__restrict__ proj, const float *__restrict__ coords, int *__restrict__ count, int V, int H, int W, int X,
+             int Y, int Z, GateGeom g, int nbx, int nby, int nbz, int total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int bps = nbx * nby * nbz;
+    const int b = i / bps, r = i % bps;
+    const int kz = r % nbz, ky = (r / nbz) % nby, kx = r / (nbz * nby);
+    const long long N = (long long)X * Y * Z;
+    int used = 0, chunks_all = 0, max_stride = 0;
+    for (int v = 0; v < V; ++v) {
+        const float *P = proj + ((long long)b * V + v) * 12;
+        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+        bool front = true;
+        for (int c = 0; c < 8; ++c) {
+            const int vx = kx * g.bx + ((c & 1) ? g.bx - 1 : 0), vy = ky * g.by + ((c & 2) ? g.by - 1 : 0), vz = kz * kBZ + ((c & 4) ? kBZ - 1 : 0);
+            const float *Xp = coords + ((long long)b * N + ((long long)vx * Y + vy) * Z + vz) * 3;
+            const float a = P[0] * Xp[0] + P[1] * Xp[1] + P[2] * Xp[2] + P[3];
+            const float bb = P[4] * Xp[0] + P[5] * Xp[1] + P[6] * Xp[2] + P[7];
+            const float z = P[8] * Xp[0] + P[9] * Xp[1] + P[10] * Xp[2] + P[11];
+            if (!(z > 0.f)) { front = false; continue; }
+            const float ix = (a / z) / (float)H * (float)(W - 1), iy = (bb / z) / (float)W * (float)(H - 1);   // quirk Q1 as in make_taps
+            xmin = fminf(xmin, ix); xmax = fmaxf(xmax, ix); ymin = fminf(ymin, iy); ymax = fmaxf(ymax, iy);
+        }
+        if (!front || xmax < xmin) continue;                                     // behind a camera: the kernels decide per block
+        const float x0 = fmaxf(floorf(xmin), -1.f), x1 = fminf(floorf(xmax), (float)(W - 1));
+        const float y0 = fmaxf(floorf(ymin), -1.f), y1 = fminf(floorf(ymax), (float)(H - 1));
+        if (x1 < x0 || y1 < y0) continue;                                        // wholly outside the image
+        const int bw = (int)(x1 - x0) + 2, bh = (int)(y1 - y0) + 2;
+        const int stride = (g.column_major ? bh : bw) | 1, lines = g.column_major ? bw : bh;
+        const int chunks = (stride * lines + 63) >> 6;
+        used += chunks << 6;
+        chunks_all += chunks;
+        max_stride = stride > max_stride ? stride : max_stride;
+    }
+    const bool fits = used <= g.cap_slots && chunks_all <= g.max_chunks && max_stride + 2 <= kZeroSlots;
+    if (!fits) atomicAdd(count, 1);
+}
+
+hipError_t launch_brick_gate(const float *proj, const float *coords, int *count, const GateGeom &g, const Problem &p, hipStream_t s)
+{
+    const int nbx = p.X / g.bx, nby = p.Y / g.by, nbz = p.Z / kBZ, total = nbx * nby * nbz * p.B;
+    hipLaunchKernelGGL(k_brick_gate, dim3((total + 255) / 256), dim3(256), 0, s, proj, coords, count, p.V, p.H, p.W, p.X, p.Y, p.Z, g,
+                       nbx, nby, nbz, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------- dispatch
+extern template hipError_t launch_fwd_method<AGG_SOFTMAX>(const void *, const float *, const float *, void *, const Problem &, int, hipStream_t);
+extern template hipError_t launch_fwd_method<AGG_SUM>(const void *, const float *, const float *, void *, const Problem &, int, hipStream_t);
+extern template hipError_t launch_fwd_method<AGG_MEAN>(const void *, const float *, const float *, void *, const Problem &, int, hipStream_t);
+extern template hipError_t launch_fwd_method<AGG_MAX>(const void *, const float *, const float *, void *, const Problem &, int, hipStream_t);
+
+// featK: column-major quad-planar fp32 copy of the features (launch_to_quad_planar_t)
+hipError_t launch_fwd_brick(const void *featK, const float *proj, const float *coords, void *out, const Problem &p, hipStream_t s)
+{
+    if (!brick_fwd_supported(p)) return hipErrorNotSupported;
+    const int nvox = brick_fwd_nvox(p);
+    switch (p.method) {
+    case AGG_SOFTMAX: return launch_fwd_method<AGG_SOFTMAX>(featK, proj, coords, out, p, nvox, s);
+    case AGG_SUM: return launch_fwd_method<AGG_SUM>(featK, proj, coords, out, p, nvox, s);
+    case AGG_MEAN: return launch_fwd_method<AGG_MEAN>(featK, proj, coords, out, p, nvox, s);
+    case AGG_MAX: return launch_fwd_method<AGG_MAX>(featK, proj, coords, out, p, nvox, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace mvhmr

@@ -446,7 +446,7 @@ def test_raw_c_abi_call(gpu):
     L = ctypes.CDLL(_capi.LIB_PATH)
     L.mvhmr_unproject_forward_workspace_bytes.restype = ctypes.c_size_t
     desc = _capi.Desc()
-    desc.abi_version = 1
+    desc.abi_version = _capi.ABI_VERSION
     desc.batch, desc.views, desc.channels, desc.feat_h, desc.feat_w = f.shape
     desc.vol_x, desc.vol_y, desc.vol_z = c.shape[1:4]
     desc.method, desc.feat_dtype, desc.out_dtype, desc.feat_layout, desc.variant = 0, 0, 0, 0, 0
