@@ -50,9 +50,55 @@ k_to_quad_planar(const TF *__restrict__ src, float4 *__restrict__ dst, int C, in
     dst[(bv * (C >> 2) + q) * HW + p] = make_float4(to_f32<TF>(s[0]), to_f32<TF>(s[HW]), to_f32<TF>(s[2 * (long long)HW]), to_f32<TF>(s[3 * (long long)HW]));
 }
 
+// Same pass for maps whose 32-row bands fit LDS: a band of one channel quad is 4 x 32 x W contiguous floats per channel, read
+// linearly (1-KiB runs per wave instruction instead of 128-B tile rows) and written as 512-B runs along y.
+template <typename TF>
+__global__ void __launch_bounds__(512)
+k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int H, int W, Gate gate)
+{
+    if (gated_off(gate)) return;
+    extern __shared__ float band[];                                              // [c][y][x], row stride W | 1
+    const int ldw = W | 1;
+    const long long bv = blockIdx.z;
+    const int q = blockIdx.y, y0 = blockIdx.x << 5;
+    const int rows = H - y0 < 32 ? H - y0 : 32;
+    const long long plane = (long long)H * W;
+    const TF *s = src + (bv * C + q * 4) * plane + (long long)y0 * W;
+    const int n = rows * W;
+    if (sizeof(TF) == 4 && (W & 3) == 0 && (plane & 3) == 0) {
+        // 16-B loads: 4 consecutive x of one row (W % 4 == 0 keeps them inside a row and aligned)
+        for (int c = 0; c < 4; ++c)
+            for (int i = threadIdx.x * 4; i < n; i += 512 * 4) {
+                const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(s) + (long long)c * plane + i);
+                const int y = i / W, x = i - y * W;
+                float *b = band + (c * 32 + y) * ldw + x;
+                b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
+            }
+    } else {
+        for (int c = 0; c < 4; ++c)
+            for (int i = threadIdx.x; i < n; i += 512) {
+                const int y = i / W, x = i - y * W;
+                band[(c * 32 + y) * ldw + x] = to_f32<TF>(s[(long long)c * plane + i]);
+            }
+    }
+    __syncthreads();
+    float4 *d = dst + (bv * (C >> 2) + q) * plane;
+    const int ty = threadIdx.x & 31;
+    if (ty < rows)
+        for (int x = threadIdx.x >> 5; x < W; x += 16)
+            d[(long long)x * H + y0 + ty] = make_float4(band[ty * ldw + x], band[(32 + ty) * ldw + x], band[(64 + ty) * ldw + x], band[(96 + ty) * ldw + x]);
+}
+
 hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s)
 {
     if (p.C % 4) return hipErrorNotSupported;
+    const size_t band_bytes = (size_t)4 * 32 * (p.W | 1) * sizeof(float);
+    if (band_bytes <= 64 * 1024) {                                               // 2+ blocks per CU
+        const dim3 grid((p.H + 31) / 32, p.C / 4, p.B * p.V);
+        if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t_band<__half>, grid, dim3(512), band_bytes, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
+        else hipLaunchKernelGGL(k_to_quad_planar_t_band<float>, grid, dim3(512), band_bytes, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
+        return hipGetLastError();
+    }
     const dim3 grid(((p.W + 31) / 32) * ((p.H + 31) / 32), p.C / 4, p.B * p.V);
     if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
     else hipLaunchKernelGGL(k_to_quad_planar_t<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
