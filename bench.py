@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Benchmark of the un-projection hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: launched by torch.distributed.run)
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--train-step]
+
+N > 1 without a launcher: this process starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child
+BEFORE anything touches the GPU and relays rank 0's JSON line (the driver's own torchrun launch is used as is).
 
 A step = one pass of the hot path (layout pass + fused un-projection kernel, through the C ABI) over one batch
 of synthetic input that is already resident in HBM.  Workload at N = 1: BASELINE.json's metric configuration --
@@ -15,6 +18,11 @@ Rank 0 prints ONE JSON line.  Besides the driver's fields it carries
                 the timed region; peak = 8 TB/s (MI355X_MICROARCH.md)
   cpu_baseline  the reference's CPU algorithm (per-(b,v) F.grid_sample loop, oracle/reference_loop_torch.py)
                 timed on this box's host cores on a bounded sample (rank 0, N = 1 only)
+  auto_call     the same step through the drop-in Python function unprojection(..., variant='auto') (one C-ABI call: gate
+                kernel + layout pass + fused kernel, workspace from the caching allocator), for comparison with `value`
+  rccl          N > 1: the path's only collective, the flat fp32 all-reduce of process_feature's gradient, in microseconds
+--train-step replaces the step by one training step of the aggregator (BASELINE configs[4]): VolumeGenerator forward, scalar
+loss, backward (1x1 conv + un-projection backward) and that all-reduce; shapes come from --grid/--channels/--batch.
 """
 import argparse
 import ctypes
@@ -50,7 +58,29 @@ def parse():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--no-backward", action="store_true", help="skip the (untimed-for-`value`) backward measurement")
     ap.add_argument("--cpu-sample-batch", type=int, default=8, help="samples of the workload timed on the host (about 15 s)")
+    ap.add_argument("--train-step", action="store_true", help="time one aggregator training step (fwd + bwd + grad all-reduce)")
+    ap.add_argument("--in-channels", type=int, default=None, help="--train-step: input channels of the 1x1 conv (default: --channels)")
     return ap.parse_args()
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: run the N ranks as a child torchrun job (this process has not
+    touched the GPU and never will) and relay what rank 0 prints."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    for l in (lines[-1:] if lines else res.stdout.splitlines()):
+        print(l, flush=True)
+    return res.returncode
 
 
 # ------------------------------------------------------------------------------------------- synthetic inputs (SURVEY.md 8d)
@@ -97,12 +127,120 @@ def frustum_stats(P, coords, H, W):
     return float(np.mean(inside)), float(np.mean(invalid))
 
 
+def time_grad_allreduce(n_floats, dev, use_rccl, world, iters=20):
+    """The path's only collective (sharding.allreduce_aggregator_grads' flat fp32 buffer): microseconds per all-reduce."""
+    import torch.distributed as dist
+    flat = torch.ones(n_floats, dtype=torch.float32, device=dev if use_rccl else "cpu")
+    for _ in range(5):
+        dist.all_reduce(flat)
+    if use_rccl:
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        dist.all_reduce(flat)
+    if use_rccl:
+        torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / iters * 1e6
+    return {"ranks": world, "allreduce_us": round(us, 1), "bytes": n_floats * 4, "backend": "rccl" if use_rccl else "gloo (ranks share a GPU)"}
+
+
+def train_step_bench(a, rank, world, dev, use_rccl):
+    """BASELINE configs[4]: one training step of the aggregator on this rank's batch shard -- VolumeGenerator forward, a
+    scalar loss, backward (1x1 conv + un-projection backward) and the flat gradient all-reduce."""
+    from multiviewhmr_amd import aggregation, sharding
+    if world > 1:
+        import torch.distributed as dist
+    B, S, C, V, HW, IMG = a.batch, a.grid, a.channels, a.views, a.feat, 384
+    Cin = a.in_channels or C
+    rng = np.random.default_rng(rank)
+    cams = [[None] * B for _ in range(V)]
+    for v in range(V):
+        az = 2 * np.pi * v / V + 0.3
+        for b in range(B):
+            eye = np.array([np.cos(az), np.sin(az), 0.0]) * rng.uniform(4500.0, 5500.0) + np.array([0, 0, 1500.0])
+            fwd = -eye / np.linalg.norm(eye)
+            right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right)
+            R = np.stack([right, np.cross(fwd, right), fwd])
+            cam = multiview.Camera(R, -R @ eye, [[1145.0, 0, 512.0], [0, 1145.0, 512.0], [0, 0, 1.0]])
+            cam.update_after_crop((200, 200, 824, 824))
+            cam.update_after_resize((624, 624), (IMG, IMG))
+            cams[v][b] = cam
+    batch = {"images": np.zeros((B, V, IMG, IMG, 3), np.uint8), "cameras": cams,
+             "keypoints_3d": [rng.normal(0, 100, (17, 3)).astype(np.float32) for _ in range(B)]}
+    torch.manual_seed(0)                                            # same initial weights on every rank
+    gen = aggregation.VolumeGenerator(volume_size=S, input_channels=Cin, output_channels=C, device=dev).train()
+    np.random.seed(rank)
+    torch.manual_seed(100 + rank)
+    feats = torch.randn(B, V, Cin, HW, HW, device=dev, requires_grad=True)
+    proj_org = torch.from_numpy(np.stack([[cams[v][b].projection for v in range(V)] for b in range(B)]).astype(np.float32)).to(dev)
+    n_grad = sum(p.numel() for p in gen.parameters())
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    parts = np.zeros(3)
+
+    def step(record=False):
+        gen.zero_grad(set_to_none=True)
+        feats.grad = None
+        t = [time.perf_counter()]
+        vol = gen(feats, proj_org, batch)
+        if record: torch.cuda.synchronize(); t.append(time.perf_counter())
+        vol.mean().backward()     # a loss without full-volume temporaries (the real consumer is the 3-D regressor)
+        if record: torch.cuda.synchronize(); t.append(time.perf_counter())
+        if world > 1:
+            sharding.allreduce_aggregator_grads(gen)
+        if record:
+            torch.cuda.synchronize(); t.append(time.perf_counter())
+            parts[:] += np.diff(t)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev if use_rccl else "cpu", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    for _ in range(2):
+        step(record=True)                                          # untimed: where the step goes (synchronising)
+    ms = elapsed / a.steps * 1e3
+    value = B * S ** 3 * V * world / (elapsed / a.steps) / 1e6
+    result = {
+        "metric": "Mvoxel*views/s, one aggregator train step (fwd + bwd + grad all-reduce)",
+        "value": round(value, 1), "unit": "Mvoxel*views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "VolumeGenerator train step: %d^3 grid, %d views, 1x1 conv %d->%d ch, %dx%d maps, batch %d per GPU, softmax"
+                               % (S, V, Cin, C, HW, HW, B), "global_batch": B * world,
+                   "parallelism": "batch-sharded x%d; flat all-reduce of %d fp32 conv gradients" % (world, n_grad)},
+        "phases_ms": {"forward": round(parts[0] / 2 * 1e3, 2), "loss_backward": round(parts[1] / 2 * 1e3, 2),
+                      "grad_allreduce": round(parts[2] / 2 * 1e3, 3)},
+    }
+    if world > 1:
+        result["rccl"] = time_grad_allreduce(n_grad, dev, use_rccl, world)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------------------------------- main
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(spawn_ranks(a.gpus))          # before any GPU call: the parent only waits for its child
     if world != a.gpus and world > 1:
         a.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
@@ -118,6 +256,9 @@ def main():
             dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
         else:
             dist.init_process_group("gloo")
+
+    if a.train_step:
+        return train_step_bench(a, rank, world, dev, use_rccl)
 
     B, S, C, V, HW = a.batch, a.grid, a.channels, a.views, a.feat
     N = S ** 3
@@ -212,6 +353,26 @@ def main():
                      "step_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
+    # The path's only collective, timed on every rank (N > 1): process_feature's flat gradient buffer (C*C + C fp32)
+    if world > 1:
+        result["rccl"] = time_grad_allreduce(C * C + C, dev, use_rccl, world)
+
+    # The same step as a reference user calls it: unprojection(features, proj, coords) with AUTO -- one C-ABI call that
+    # runs the device-side geometry gate, the layout pass and the fused kernel, workspace from the caching allocator.
+    if rank == 0 and world == 1:
+        from multiviewhmr_amd import aggregation
+        ea = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        with torch.no_grad():
+            for it in range(13):
+                if it == 3: ea[0].record()
+                o2 = aggregation.unprojection(feats, proj, coords, aggregation_method=a.method, variant="auto")
+            ea[1].record()
+        torch.cuda.synchronize()
+        ms_auto = ea[0].elapsed_time(ea[1]) / 10
+        result["auto_call"] = {"ms": round(ms_auto, 4), "value": round(B * N * V / (ms_auto * 1e-3) / 1e6, 1), "unit": "Mvoxel*views/s",
+                               "what": "aggregation.unprojection(features, proj, coords, variant='auto'): gate + layout pass + kernel in one call"}
+        del o2
+
     # Backward (gradient w.r.t. the features), reported beside the headline: SURVEY.md 8(d) quotes fwd and fwd+bwd
     # separately.  Outside the timed region of `value`; grad_out = the forward output (same shape, realistic values).
     if rank == 0 and world == 1 and not a.no_backward:
@@ -242,6 +403,7 @@ def main():
                 tj = json.load(open(traffic))
                 if tj.get("workload_key") == "%d-%d-%d-%d-%d-%s" % (S, C, V, HW, B, a.dtype):
                     result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
+                    result["roofline"]["traffic_source"] = "replayed from %s (separate rocprofv3 --pmc passes, not this run)" % os.path.relpath(traffic, ROOT)
             except Exception:
                 pass
         inside, invalid = frustum_stats(P_np[0], coords_np[0], HW, HW)
@@ -262,8 +424,8 @@ def main():
             dt = time.perf_counter() - t1
             result["cpu_baseline"] = {"value": round(nb * N * V / dt / 1e6, 4), "unit": "Mvoxel*views/s",
                                       "cores": torch.get_num_threads(), "kind": "port",
-                                      "sample": "%d of %d samples of the same workload, per-(b,v) F.grid_sample loop "
-                                                "(oracle/reference_loop_torch.py), %.1f s, host has %d cpus"
+                                      "sample": "%d of %d samples of the same workload (samples are independent: the full batch is this rate, "
+                                                "not re-timed), per-(b,v) F.grid_sample loop (oracle/reference_loop_torch.py), %.1f s, host has %d cpus"
                                                 % (nb, B, dt, os.cpu_count())}
         print(json.dumps(result), flush=True)
     if world > 1:
