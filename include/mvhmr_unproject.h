@@ -119,6 +119,13 @@ int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *featur
  * Scatter-adds use fp32 float atomics, so low-order bits can differ from run to run.  The brick variant sums a
  * brick's contributions per pixel in fixed point first (one power-of-two scale per channel, resolution ~2^-25 of the
  * channel's largest contribution in the brick) and issues one float atomic per window pixel.
+ * Non-finite values: an Inf / NaN in grad_out (or an overflowing product) makes grad_features non-finite.  The gather variant
+ * propagates it tap by tap like the reference's float scatter; the brick variant writes NaN to every pixel of the affected
+ * brick's tap windows for that channel (a superset of the reference's pixels) -- isfinite(grad) agrees, the exact set differs.
+ * Forward: a tap outside the image contributes 0 * (clamped border pixel) instead of being skipped.  With a NON-FINITE feature
+ * value in a border pixel the same samples come out non-finite as with grid_sample's zero padding (such a sample also taps the
+ * border pixel itself), but an Inf may read NaN; finite outputs are never affected.  A NaN depth (NaN in proj / coords) gives
+ * an exactly zero sample for that view.
  */
 int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_out, const void *features,
                              const float *proj, const float *coords, void *grad_features, void *workspace,
@@ -160,6 +167,10 @@ int mvhmr_unproject_selected_variant(const mvhmr_unproject_desc *desc);
  */
 int mvhmr_unproject_query_variant(const mvhmr_unproject_desc *desc, const float *proj, const float *coords,
                                   void *hip_stream);
+
+/* Testing hook: the key under which the library remembers that it raised a kernel's dynamic-LDS limit (the attribute is
+ * per device AND kernel; a second GPU driven from the same process must get its own opt-in). */
+unsigned long long mvhmr_internal_lds_cache_key(int device, const void *kernel);
 
 int mvhmr_abi_version(void);
 const char *mvhmr_status_string(int status);

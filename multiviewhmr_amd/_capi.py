@@ -20,7 +20,7 @@ EXPORTS = (
     "mvhmr_unproject_forward_workspace_bytes", "mvhmr_unproject_backward_workspace_bytes",
     "mvhmr_unproject_forward", "mvhmr_unproject_backward", "mvhmr_build_coord_volumes",
     "mvhmr_unproject_selected_variant", "mvhmr_preferred_layout", "mvhmr_feature_layout_bytes", "mvhmr_convert_features",
-    "mvhmr_unproject_query_variant",
+    "mvhmr_unproject_query_variant", "mvhmr_internal_lds_cache_key",
 )
 
 
@@ -67,6 +67,8 @@ def lib():
     L.mvhmr_feature_layout_bytes.argtypes = [dp, ctypes.c_int]
     L.mvhmr_convert_features.restype = ctypes.c_int
     L.mvhmr_convert_features.argtypes = [dp, vp, ctypes.c_int, vp, vp]
+    L.mvhmr_internal_lds_cache_key.restype = ctypes.c_ulonglong
+    L.mvhmr_internal_lds_cache_key.argtypes = [ctypes.c_int, vp]
     L.mvhmr_build_coord_volumes.restype = ctypes.c_int
     L.mvhmr_build_coord_volumes.argtypes = [vp, vp, vp, i32, i32, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), vp]

@@ -166,6 +166,8 @@ extern "C" {
 
 int mvhmr_abi_version(void) { return MVHMR_ABI_VERSION; }
 
+unsigned long long mvhmr_internal_lds_cache_key(int device, const void *kernel) { return dynamic_lds_cache_key(device, kernel); }
+
 const char *mvhmr_last_error(void) { return g_err; }
 
 const char *mvhmr_status_string(int status)

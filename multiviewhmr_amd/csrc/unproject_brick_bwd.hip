@@ -284,10 +284,12 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 aggregate_grad<METHOD, VT>(s[i], g[i], ds[i]);
-                float big = 0.f;
+                // max |ds| on the BITS (sign cleared): non-negative floats order as ints, and Inf / NaN (>= 0x7f800000) sort above
+                // every finite value instead of being dropped as fmaxf drops a NaN -- a non-finite gradient must stay visible
+                int big = 0;
 #pragma unroll
-                for (int v = 0; v < VT; ++v) big = fmaxf(big, fabsf(ds[i][v]));
-                const int bb = wave_max_dpp(__builtin_bit_cast(int, big));       // non-negative floats order as ints
+                for (int v = 0; v < VT; ++v) { const int a = __builtin_bit_cast(int, ds[i][v]) & 0x7fffffff; big = a > big ? a : big; }
+                const int bb = wave_max_dpp(big);
                 if (lane == 0) atomicMax(&sh->aux[(q & 1) * 4 + i], bb);            // one scale per channel of the quad
             }
         };
@@ -316,6 +318,10 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 se = se < 1 ? 1 : (se > 254 ? 254 : se);
                 scale[i] = bbits == 0 ? 0.f : __builtin_bit_cast(float, se << 23);
                 inv_scale[i] = bbits == 0 ? 0.f : __builtin_bit_cast(float, (254 - se) << 23);
+                // a non-finite |ds| somewhere in the brick (overflowed or NaN grad_out): fixed point cannot carry it.  The channel
+                // adds nothing (scale 0) and the flush writes NaN to every live pixel of the brick's windows instead -- a superset
+                // of the pixels the reference's float scatter would poison, so that isfinite() checks downstream still trip.
+                if (bbits >= 0x7f800000) { scale[i] = 0.f; inv_scale[i] = __builtin_nanf(""); }
             }
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
@@ -359,7 +365,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                     int *pl = iplanes + ch * plane_floats + c_slot[r] + srcl;
                     const int iv = *pl;
                     *pl = 0;                                                      // ready for the next quad
-                    const bool add = (off & 1u) && iv != 0;
+                    const bool add = (off & 1u) && (iv != 0 || inv_ch != inv_ch);   // poisoned channel (inv_ch is NaN): every live pixel
                     if (__builtin_amdgcn_ballot_w64(add) != 0) {                   // wave-uniform: the instruction is issued or not
                         if (add) atomicAdd(gq + (off >> 2) + ch, (float)iv * inv_ch);
                         ++n_at;

@@ -98,6 +98,13 @@ k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const
             for (int v = 0; v < VT; ++v) {
                 const UTap u = uniform_rec(recs[j * VT + v]);
                 const TF *fv = fb + v * mapsz;
+                // a sample that is identically zero (z <= 0, or all four taps outside the map) reads nothing: its dummy taps
+                // must not turn a non-finite pixel (0, 0) into 0 * Inf (wave-uniform branch)
+                if (u.w00 == 0.f && u.w01 == 0.f && u.w10 == 0.f && u.w11 == 0.f) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s[i][v] = 0.f;
+                    continue;
+                }
                 const f32x4 a = Vec4<TF>::load(fv + u.o00), bb = Vec4<TF>::load(fv + u.o01);
                 const f32x4 c = Vec4<TF>::load(fv + u.o10), d = Vec4<TF>::load(fv + u.o11);
 #pragma unroll
@@ -112,6 +119,11 @@ k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const
             for (int v = 0; v < V; ++v) {
                 const UTap u = uniform_rec(recs[j * V + v]);
                 const TF *fv = fb + v * mapsz;
+                if (u.w00 == 0.f && u.w01 == 0.f && u.w10 == 0.f && u.w11 == 0.f) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) ra[i].push(0.f);
+                    continue;
+                }
                 const f32x4 a = Vec4<TF>::load(fv + u.o00), bb = Vec4<TF>::load(fv + u.o01);
                 const f32x4 c = Vec4<TF>::load(fv + u.o10), d = Vec4<TF>::load(fv + u.o11);
 #pragma unroll
@@ -189,6 +201,11 @@ k_bwd_gather(const TO *__restrict__ grad_out, const TF *__restrict__ featT, cons
 
     auto sample4 = [&](const UTap &u, int v, float (&sv)[4]) {
         const TF *fv = fb + v * mapsz;
+        if (u.w00 == 0.f && u.w01 == 0.f && u.w10 == 0.f && u.w11 == 0.f) {        // identically zero: reads nothing (see k_fwd_gather)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sv[i] = 0.f;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             sv[i] = bilerp(to_f32<TF>(fv[u.o00 + ch[i]]), to_f32<TF>(fv[u.o01 + ch[i]]), to_f32<TF>(fv[u.o10 + ch[i]]),

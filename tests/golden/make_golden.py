@@ -255,6 +255,9 @@ def volgen_cases():
                     kind="coco", training=True, use_tri=False, seed=13)
     run_volgen_case("eval_tri", B=2, V=4, C_in=4, C_out=2, S=4, feat_hw=(12, 12), image_hw=(48, 48),
                     kind="mpii", training=False, use_tri=True, seed=14)
+    # the only combination in which the triangulated pivot reaches the output: training (theta != 0) + use_triangulation
+    run_volgen_case("train_tri", B=3, V=4, C_in=4, C_out=4, S=6, feat_hw=(12, 12), image_hw=(48, 48),
+                    kind="mpii", training=True, use_tri=True, seed=15)
 
 
 # --------------------------------------------------------------------------- geometry helpers
