@@ -426,16 +426,16 @@ def test_volume_generator_end_to_end(case, gpu):
     rots, centers = gen.volume_pose(batch, _dev(d, "proj_org", gpu), tuple(batch["images"].shape[2:-1]))
     coords = gen.coord_volumes(rots, centers, gpu)
     tri = bool(int(d["meta"][6]))
-    # use_triangulation: the pivot is a DLT null vector.  The reference takes it from a per-sample fp32 torch.svd whose low bits
-    # depend on the SVD backend (its own CPU and GPU runs differ by the same amount); this build solves the same system once,
-    # batched, in float64 on the device.  The two pivots differ by <= 5e-2 mm (voxel pitch: 400+ mm at these sizes), which moves
-    # every voxel of a rotated volume by as much -- hence the coordinate / volume bounds of the *_tri cases.
-    record_err("volgen coords %s (mm)" % case, _err(coords.cpu().numpy(), d["coords"]), 5e-2 if tri else 1e-3)
+    # use_triangulation: the pivot is a DLT null vector.  The reference takes it from a per-sample fp32 torch.svd; this build
+    # solves the same system once, batched, in float64 on the device.  Observed (profiles/r02_parity_observed.json): the
+    # coordinates of the train_tri golden (training + triangulation, the one case where the pivot reaches the output) agree
+    # to 2.4e-4 mm and its volume to 1.1e-6 -- the same bounds as every other case hold.
+    record_err("volgen coords %s (mm)" % case, _err(coords.cpu().numpy(), d["coords"]), 1e-3)
     np.random.seed(seed)
     with torch.no_grad():
         vol = gen(_dev(d, "features_in", gpu), _dev(d, "proj_org", gpu), batch)
     assert vol.dtype == torch.float32 and tuple(vol.shape) == d["volume"].shape
-    record_err("volgen volume %s" % case, _err(vol.cpu().numpy(), d["volume"]), 2e-3 if tri else TOL)
+    record_err("volgen volume %s" % case, _err(vol.cpu().numpy(), d["volume"]), TOL)
 
 
 def test_volume_generator_trains(gpu):
