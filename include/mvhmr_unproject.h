@@ -132,6 +132,25 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
                              size_t workspace_bytes, void *hip_stream);
 
 /*
+ * The same two calls for the volumes VolumeGenerator.forward builds (models/aggregation.py:138-187): instead of reading a
+ * (B,X,Y,Z,3) coordinate tensor the kernels evaluate the reference's recipe per voxel,
+ *     coords[b,i,j,k] = rot[b] @ (position + sides / (S - 1) * (i,j,k) - center[b]) + center[b],      S = (vol_x, vol_y, vol_z)
+ * with the rounding order of mvhmr_build_coord_volumes, so that both routes are bit-equal.  13 floats per sample replace the
+ * coordinate tensor (403 MB per GPU at BASELINE configs[4]) and the kernel that builds it.
+ *   rot       (B,9) fp32 row-major, device   -- utils/volumetric.py:87-114 (identity at eval)
+ *   center    (B,3) fp32, device             -- the rotation pivot, aggregation.py:180-186
+ *   position, sides   3 doubles each, HOST   -- cuboid corner and edge lengths, aggregation.py:143-144
+ */
+int mvhmr_unproject_forward_cuboid(const mvhmr_unproject_desc *desc, const void *features, const float *proj,
+                                   const float *rot, const float *center, const double position[3],
+                                   const double sides[3], void *out, void *workspace, size_t workspace_bytes,
+                                   void *hip_stream);
+int mvhmr_unproject_backward_cuboid(const mvhmr_unproject_desc *desc, const void *grad_out, const void *features,
+                                    const float *proj, const float *rot, const float *center,
+                                    const double position[3], const double sides[3], void *grad_features,
+                                    void *workspace, size_t workspace_bytes, void *hip_stream);
+
+/*
  * Layout pass on its own: features (B,V,C,Hf,Wf) -> dst in `dst_layout` (MVHMR_LAYOUT_BVHWC with the channel
  * count rounded up to a multiple of 4 and zero padded, or MVHMR_LAYOUT_QUAD), desc->feat_dtype.
  * mvhmr_unproject_forward runs the pass its kernel needs into its workspace when desc->feat_layout is

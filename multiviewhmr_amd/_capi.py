@@ -21,6 +21,7 @@ EXPORTS = (
     "mvhmr_unproject_forward", "mvhmr_unproject_backward", "mvhmr_build_coord_volumes",
     "mvhmr_unproject_selected_variant", "mvhmr_preferred_layout", "mvhmr_feature_layout_bytes", "mvhmr_convert_features",
     "mvhmr_unproject_query_variant", "mvhmr_internal_lds_cache_key",
+    "mvhmr_unproject_forward_cuboid", "mvhmr_unproject_backward_cuboid",
 )
 
 
@@ -61,6 +62,11 @@ def lib():
     L.mvhmr_unproject_forward.argtypes = [dp, vp, vp, vp, vp, vp, sz, vp]
     L.mvhmr_unproject_backward.restype = ctypes.c_int
     L.mvhmr_unproject_backward.argtypes = [dp, vp, vp, vp, vp, vp, vp, sz, vp]
+    d3 = ctypes.POINTER(ctypes.c_double)
+    L.mvhmr_unproject_forward_cuboid.restype = ctypes.c_int
+    L.mvhmr_unproject_forward_cuboid.argtypes = [dp, vp, vp, vp, vp, d3, d3, vp, vp, sz, vp]
+    L.mvhmr_unproject_backward_cuboid.restype = ctypes.c_int
+    L.mvhmr_unproject_backward_cuboid.argtypes = [dp, vp, vp, vp, vp, vp, d3, d3, vp, vp, sz, vp]
     L.mvhmr_preferred_layout.restype = ctypes.c_int
     L.mvhmr_preferred_layout.argtypes = [dp]
     L.mvhmr_feature_layout_bytes.restype = sz

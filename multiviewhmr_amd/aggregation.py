@@ -53,11 +53,13 @@ def _dtype_code(dt):
 
 
 def _make_desc(features, coord_volumes, method, out_dtype, layout, variant):
+    """coord_volumes: the (B,X,Y,Z,3) tensor, or just its (X, Y, Z)"""
     B, V, C, Hf, Wf = features.shape
     d = _capi.Desc()
     d.abi_version = _capi.ABI_VERSION
     d.batch, d.views, d.channels, d.feat_h, d.feat_w = B, V, C, Hf, Wf
-    d.vol_x, d.vol_y, d.vol_z = (int(s) for s in coord_volumes.shape[1:4])
+    vol = tuple(coord_volumes.shape[1:4]) if torch.is_tensor(coord_volumes) else tuple(coord_volumes)
+    d.vol_x, d.vol_y, d.vol_z = (int(s) for s in vol)
     d.method = method
     d.feat_dtype = _dtype_code(features.dtype)
     d.out_dtype = _dtype_code(out_dtype)
@@ -149,6 +151,84 @@ def unprojection(features, proj_matricies, coord_volumes, aggregation_method='so
     return _Unprojection.apply(features, proj, coords, _capi.AGG[aggregation_method], out_dtype, _capi.VARIANT[variant])
 
 
+class _UnprojectionCuboid(torch.autograd.Function):
+    """The same kernels fed by the cuboid recipe instead of a coordinate tensor (mvhmr_unproject_*_cuboid)."""
+
+    @staticmethod
+    def forward(ctx, features, proj, rot, center, position, sides, vol, method, out_dtype, variant):
+        L = _capi.lib()
+        layout = _capi.LAYOUT_BVHWC if _is_channels_last5(features) else _capi.LAYOUT_BVCHW
+        if layout == _capi.LAYOUT_BVCHW:
+            features = features.contiguous()
+        desc = _make_desc(features, vol, method, out_dtype, layout, variant)
+        pos = (ctypes.c_double * 3)(*[float(x) for x in position])
+        sid = (ctypes.c_double * 3)(*[float(x) for x in sides])
+        B, C = features.shape[0], features.shape[2]
+        with torch.cuda.device(features.device):
+            out = torch.empty((B, C) + tuple(vol), dtype=out_dtype, device=features.device)
+            ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), features.device)
+            _capi.check(L.mvhmr_unproject_forward_cuboid(ctypes.byref(desc), _ptr(features), _ptr(proj), _ptr(rot), _ptr(center), pos, sid,
+                                                         _ptr(out), wsp, 0 if ws is None else ws.numel(), _stream(features.device)))
+        ctx.save_for_backward(features, proj, rot, center)
+        ctx.desc, ctx.pos, ctx.sid = desc, pos, sid
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        features, proj, rot, center = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return (None,) * 10
+        L = _capi.lib()
+        desc = ctx.desc
+        grad_out = grad_out.contiguous()
+        with torch.cuda.device(features.device):
+            grad_features = torch.empty_like(features)
+            ws, wsp = _workspace(L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc)), features.device)
+            _capi.check(L.mvhmr_unproject_backward_cuboid(ctypes.byref(desc), _ptr(grad_out), _ptr(features), _ptr(proj), _ptr(rot),
+                                                          _ptr(center), ctx.pos, ctx.sid, _ptr(grad_features), wsp,
+                                                          0 if ws is None else ws.numel(), _stream(features.device)))
+        return (grad_features,) + (None,) * 9
+
+
+def unprojection_cuboid(features, proj_matricies, rotations, centers, position, sides, volume_shape,
+                        aggregation_method='softmax', *, out_dtype=None, variant='auto'):
+    """`unprojection` for the volumes VolumeGenerator builds (aggregation.py:138-187), without the coordinate tensor: voxel centres
+    are rot[b] @ (position + sides / (S - 1) * (i,j,k) - center[b]) + center[b], evaluated inside the kernels (bit-equal to
+    mvhmr_build_coord_volumes followed by `unprojection`).
+
+    rotations (B,3,3) and centers (B,3): float32 tensors on features.device; position, sides: 3 numbers each (cuboid corner and
+    edge lengths); volume_shape: (X, Y, Z)."""
+    for t in (features, proj_matricies, rotations, centers):
+        if not torch.is_tensor(t):
+            raise TypeError(_TYPE_MSG)
+    if aggregation_method not in _METHODS:
+        raise ValueError("Unknown aggregation_method: {}".format(aggregation_method))
+    if variant not in _capi.VARIANT:
+        raise ValueError("Unknown kernel variant: {}".format(variant))
+    if features.dim() != 5:
+        raise RuntimeError("unprojection: features must be (B, V, C, Hf, Wf), got %s" % (tuple(features.shape),))
+    B, V = features.shape[:2]
+    if tuple(proj_matricies.shape) != (B, V, 3, 4):
+        raise RuntimeError("unprojection: proj_matricies must be (%d, %d, 3, 4), got %s" % (B, V, tuple(proj_matricies.shape)))
+    if tuple(rotations.shape) != (B, 3, 3) or tuple(centers.shape) != (B, 3):
+        raise RuntimeError("unprojection: rotations must be (%d, 3, 3) and centers (%d, 3), got %s and %s"
+                           % (B, B, tuple(rotations.shape), tuple(centers.shape)))
+    if not features.is_cuda:
+        raise RuntimeError("unprojection: features live on %s; this implementation runs only on a HIP device "
+                           "(MI355X) and has no CPU path" % features.device)
+    vol = tuple(int(v) for v in volume_shape)
+    if out_dtype is None:
+        out_dtype = torch.float16 if features.dtype == torch.float16 else torch.float32
+    if features.numel() == 0 or min(vol) == 0:
+        return torch.zeros((B, features.shape[2]) + vol, dtype=out_dtype, device=features.device)
+    dev = features.device
+    proj = proj_matricies.detach().to(device=dev, dtype=torch.float32).contiguous()
+    rot = rotations.detach().to(device=dev, dtype=torch.float32).contiguous()
+    cen = centers.detach().to(device=dev, dtype=torch.float32).contiguous()
+    return _UnprojectionCuboid.apply(features, proj, rot, cen, tuple(position), tuple(sides), vol, _capi.AGG[aggregation_method],
+                                     out_dtype, _capi.VARIANT[variant])
+
+
 # --------------------------------------------------------------------------------------- caller side
 def feature_level_projections(cameras, images_shape, features_shape):
     """(B, V, 3, 4) float32 numpy: projection matrices at feature-map resolution.
@@ -174,6 +254,35 @@ def feature_level_projections(cameras, images_shape, features_shape):
     P = P + K[..., :, 1:2] * Rt[..., 1:2, :]
     P = P + K[..., :, 2:3] * Rt[..., 2:3, :]
     return P.astype(np.float32)
+
+
+def pack_cameras(cameras, device):
+    """One pass over batch['cameras'] (list[V] of list[B] of Camera) -> float64 device tensors K (B,V,3,3) and Rt (B,V,3,4).
+    A data loader that hands `batch['cameras_packed'] = pack_cameras(...)` (or builds the two tensors itself) lets
+    VolumeGenerator.forward derive the feature-level projection matrices on the device: no Python loop over B x V cameras and no
+    host-to-device copy per call."""
+    V, B = len(cameras), len(cameras[0])
+    K = np.array([[cameras[v][b].K for v in range(V)] for b in range(B)], dtype=np.float64)
+    Rt = np.array([[np.hstack([cameras[v][b].R, cameras[v][b].t]) for v in range(V)] for b in range(B)], dtype=np.float64)
+    return {"K": torch.from_numpy(K).to(device), "Rt": torch.from_numpy(Rt).to(device)}
+
+
+def feature_level_projections_device(packed, images_shape, features_shape):
+    """feature_level_projections on the device from packed cameras: the same float64 operations in the same order
+    (update_after_resize incl. quirk Q3, then K @ [R|t] as a k-ordered sum of products), cast to float32 at the end."""
+    height, width = images_shape
+    new_width, new_height = features_shape
+    sx, sy = new_width / width, new_height / height
+    K = packed["K"].clone()
+    Rt = packed["Rt"]
+    K[..., 0, 0] = K[..., 0, 0] * sx
+    K[..., 1, 1] = K[..., 1, 1] * sy
+    K[..., 0, 2] = K[..., 0, 2] * sx
+    K[..., 1, 2] = K[..., 1, 2] * sy
+    P = K[..., :, 0:1] * Rt[..., 0:1, :]
+    P = P + K[..., :, 1:2] * Rt[..., 1:2, :]
+    P = P + K[..., :, 2:3] * Rt[..., 2:3, :]
+    return P.to(torch.float32)
 
 
 class VolumeGenerator(nn.Module):
@@ -215,19 +324,24 @@ class VolumeGenerator(nn.Module):
         image centre when use_triangulation is set."""
         batch_size = proj_matricies_org.shape[0]
         axis = self.rotation_axis()
-        rots = np.empty((batch_size, 3, 3), dtype=np.float32)
-        for b in range(batch_size):
-            theta = np.random.uniform(0.0, 2 * np.pi) if self.training else 0.0
-            rots[b] = volumetric.get_rotation_matrix(axis, theta)
+        if self.training:
+            # one draw per sample, in order, from the GLOBAL numpy stream (Q6): a sized draw consumes the same stream
+            thetas = np.random.uniform(0.0, 2 * np.pi, size=batch_size)
+            rots = volumetric.get_rotation_matrices(axis, thetas).astype(np.float32)
+        else:
+            rots = np.broadcast_to(volumetric.get_rotation_matrix(axis, 0.0).astype(np.float32), (batch_size, 3, 3))
         if self.use_triangulation:
             # one batched DLT on the device, no per-sample .cpu() (SURVEY 8(f) row 4); stays a device tensor
             n_views = proj_matricies_org.shape[1]
             images_center = (torch.tensor(images_shape, dtype=torch.float32) / 2).expand(n_views, 2)
             centers = multiview.triangulate_points_from_multiple_views_linear_batch(proj_matricies_org.detach(), images_center)
         else:
-            centers = torch.from_numpy(np.stack([np.asarray(batch['keypoints_3d'][b][6, :3], dtype=np.float32)
-                                                 for b in range(batch_size)]))
-        return torch.from_numpy(rots), centers
+            kp = batch['keypoints_3d']
+            if torch.is_tensor(kp):                                          # already a (B, 17, 3|4) tensor (any device)
+                centers = kp[:, 6, :3].to(torch.float32)
+            else:
+                centers = torch.from_numpy(np.stack([np.asarray(kp[b][6, :3], dtype=np.float32) for b in range(batch_size)]))
+        return torch.from_numpy(np.ascontiguousarray(rots)), centers
 
     def coord_volumes(self, rots, centers, device):
         """(B,S,S,S,3) float32 on `device`: rot @ (grid - center) + center, built by one kernel
@@ -251,14 +365,20 @@ class VolumeGenerator(nn.Module):
         device = features.device
 
         proj_org = proj_matricies                                           # only read (reference clones, :124)
-        proj = torch.from_numpy(feature_level_projections(batch['cameras'], images_shape, features_shape)).to(device)
+        if 'cameras_packed' in batch:                                       # device tensors: no camera loop, no H2D copy
+            proj = feature_level_projections_device(batch['cameras_packed'], images_shape, features_shape)
+        else:
+            proj = torch.from_numpy(feature_level_projections(batch['cameras'], images_shape, features_shape)).to(device)
         rots, centers = self.volume_pose(batch, proj_org, images_shape)
-        coord_volumes = self.coord_volumes(rots, centers, device)
 
         features = features.view(-1, *features.shape[2:])
         features = self.process_feature(features)
         features = features.view(batch_size, n_views, *features.shape[1:])
-        return unprojection(features, proj, coord_volumes, aggregation_method=self.aggregation_method)
+        # the coordinate volumes (aggregation.py:138-187) are never materialised: the kernels evaluate the cuboid recipe per voxel
+        cub = self.cuboid()
+        S = self.volume_size
+        return unprojection_cuboid(features, proj, rots.to(device), centers.to(device), cub.position, cub.sides, (S, S, S),
+                                   aggregation_method=self.aggregation_method)
 
 
 def build_volume_generator(cfg):

@@ -73,7 +73,7 @@ __host__ __device__ inline int fwd_cap2(int slots) { return ((slots - 2 * kZeroS
 
 template <int METHOD, int VT, int NT, typename TO, int NVOX>
 __global__ void __launch_bounds__(NT)
-k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, const float *__restrict__ coords,
+k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords,
             TO *__restrict__ out, int C, int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample,
             int lds_slots, int total_blocks, Gate gate)
 {
@@ -121,8 +121,8 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         for (int u = 0; u < NVOX; ++u) {
             const int vx = kx * BXK + (col & 3) + kBX * u;
             vox[u] = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_supported)
-            const float *Xp = coords + ((long long)b * N + vox[u]) * 3;
-            const float c0 = Xp[0], c1 = Xp[1], c2 = Xp[2];
+            float c0, c1, c2;
+            voxel_xyz(coords, b, N, vox[u], c0, c1, c2);
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
                 const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
@@ -361,7 +361,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
 int fwd_lds_slots();                                  // 16-B LDS slots of the ring (one block per CU owns all 160 KiB)
 
 template <int METHOD, int VT, int NT, typename TO, int NVOX>
-hipError_t launch_fwd_instance(const float4 *featK, const float *proj, const float *coords, TO *out, const Problem &p, hipStream_t s)
+hipError_t launch_fwd_instance(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s)
 {
     const int nbx = p.X / (kBX * NVOX), nby = p.Y / (NT / 128), nbz = p.Z / kBZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
@@ -378,7 +378,7 @@ hipError_t launch_fwd_instance(const float4 *featK, const float *proj, const flo
 
 // one aggregation method: views x storage type x voxels per lane
 template <int METHOD>
-hipError_t launch_fwd_method(const void *featK_, const float *proj, const float *coords, void *out, const Problem &p, int nvox, hipStream_t s)
+hipError_t launch_fwd_method(const void *featK_, const float *proj, const Coords &coords, void *out, const Problem &p, int nvox, hipStream_t s)
 {
     const float4 *featK = static_cast<const float4 *>(featK_);
 #define MVHMR_FWD_CASE(NVIEWS, NTHR, NV)                                                                                                 \

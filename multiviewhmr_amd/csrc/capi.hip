@@ -132,7 +132,7 @@ constexpr size_t kGateBytes = 256;
 size_t conv_bytes(const Problem &p) { const size_t a = featT_bytes(p), b = brick_workspace_bytes(p); return a > b ? a : b; }
 
 // zeroes the counter at the end of the workspace region `at`, counts the overflowing bricks, arms the gate in p
-int arm_gate(Problem &p, unsigned char *at, const float *proj, const float *coords, const GateGeom &g, hipStream_t s)
+int arm_gate(Problem &p, unsigned char *at, const float *proj, const Coords &coords, const GateGeom &g, hipStream_t s)
 {
     int *count = reinterpret_cast<int *>(at);
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
@@ -150,6 +150,29 @@ int check_ws(void *ws, size_t have, size_t need)
     if (!ws) return fail(MVHMR_ERR_WORKSPACE, "workspace is null but %zu bytes are required", need);
     if (have < need) return fail(MVHMR_ERR_WORKSPACE, "workspace has %zu bytes, %zu are required", have, need);
     if (reinterpret_cast<uintptr_t>(ws) % kAlign) return fail(MVHMR_ERR_WORKSPACE, "workspace must be %zu-byte aligned", kAlign);
+    return MVHMR_OK;
+}
+
+Coords coords_from_tensor(const float *coords, const Problem &p)
+{
+    Coords c{};
+    c.ptr = coords; c.Y = p.Y; c.Z = p.Z;
+    return c;
+}
+
+// the reference's cuboid recipe (aggregation.py:140-187): corner `position`, edge lengths `sides` (float64 on the host, cast to
+// fp32 when they meet the tensor), per-sample rotation and pivot on the device
+int coords_from_cuboid(const float *rot, const float *center, const double position[3], const double sides[3], const Problem &p, Coords *out)
+{
+    if (!rot || !center || !position || !sides) return fail(MVHMR_ERR_INVALID_ARGUMENT, "rot / center / position / sides must be non-null");
+    Coords c{};
+    c.ptr = nullptr; c.rot = rot; c.center = center; c.Y = p.Y; c.Z = p.Z;
+    c.px = (float)position[0]; c.py = (float)position[1]; c.pz = (float)position[2];
+    // step = sides / (S - 1) in float64, then fp32 (aggregation.py:157-159); a one-voxel axis has no step
+    c.sx = p.X > 1 ? (float)(sides[0] / (double)(p.X - 1)) : 0.f;
+    c.sy = p.Y > 1 ? (float)(sides[1] / (double)(p.Y - 1)) : 0.f;
+    c.sz = p.Z > 1 ? (float)(sides[2] / (double)(p.Z - 1)) : 0.f;
+    *out = c;
     return MVHMR_OK;
 }
 
@@ -203,7 +226,7 @@ int mvhmr_unproject_query_variant(const mvhmr_unproject_desc *desc, const float 
     if (hipMalloc(&count, sizeof(int)) != hipSuccess) { fail(MVHMR_ERR_LAUNCH, "query: allocation failed"); return -1; }
     hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
     const GateGeom g = brick_fwd_gate_geom(p);
-    if (e == hipSuccess) e = launch_brick_gate(proj, coords, count, g, p, s);
+    if (e == hipSuccess) e = launch_brick_gate(proj, coords_from_tensor(coords, p), count, g, p, s);
     if (e == hipSuccess) e = hipMemcpyAsync(&host, count, sizeof(int), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     (void)hipFree(count);
@@ -231,13 +254,11 @@ size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc
     return need;
 }
 
-int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *features, const float *proj, const float *coords,
-                            void *out, void *workspace, size_t workspace_bytes, void *hip_stream)
+static int forward_impl(const mvhmr_unproject_desc *desc, Problem &p, const void *features, const float *proj, const Coords &coords,
+                        void *out, void *workspace, size_t workspace_bytes, void *hip_stream)
 {
-    Problem p;
-    int rc = check_desc(desc, &p);
-    if (rc != MVHMR_OK) return rc;
-    if (!features || !proj || !coords || !out) return fail(MVHMR_ERR_INVALID_ARGUMENT, "features / proj / coords / out must be non-null");
+    int rc;
+    if (!features || !proj || !out) return fail(MVHMR_ERR_INVALID_ARGUMENT, "features / proj / out must be non-null");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const int variant = pick_variant(desc, p);
     rc = variant_conflict(desc, p, variant);
@@ -278,14 +299,35 @@ int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *featur
     return launched(launch_fwd_gather(featT, proj, coords, out, p, s), "gather forward");
 }
 
-int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_out, const void *features, const float *proj,
-                             const float *coords, void *grad_features, void *workspace, size_t workspace_bytes, void *hip_stream)
+int mvhmr_unproject_forward(const mvhmr_unproject_desc *desc, const void *features, const float *proj, const float *coords,
+                            void *out, void *workspace, size_t workspace_bytes, void *hip_stream)
 {
     Problem p;
     int rc = check_desc(desc, &p);
     if (rc != MVHMR_OK) return rc;
-    if (!grad_out || !features || !proj || !coords || !grad_features)
-        return fail(MVHMR_ERR_INVALID_ARGUMENT, "grad_out / features / proj / coords / grad_features must be non-null");
+    if (!coords) return fail(MVHMR_ERR_INVALID_ARGUMENT, "coords must be non-null");
+    return forward_impl(desc, p, features, proj, coords_from_tensor(coords, p), out, workspace, workspace_bytes, hip_stream);
+}
+
+int mvhmr_unproject_forward_cuboid(const mvhmr_unproject_desc *desc, const void *features, const float *proj, const float *rot,
+                                   const float *center, const double position[3], const double sides[3], void *out, void *workspace,
+                                   size_t workspace_bytes, void *hip_stream)
+{
+    Problem p;
+    int rc = check_desc(desc, &p);
+    if (rc != MVHMR_OK) return rc;
+    Coords cs;
+    rc = coords_from_cuboid(rot, center, position, sides, p, &cs);
+    if (rc != MVHMR_OK) return rc;
+    return forward_impl(desc, p, features, proj, cs, out, workspace, workspace_bytes, hip_stream);
+}
+
+static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const void *grad_out, const void *features, const float *proj,
+                         const Coords &coords, void *grad_features, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    int rc;
+    if (!grad_out || !features || !proj || !grad_features)
+        return fail(MVHMR_ERR_INVALID_ARGUMENT, "grad_out / features / proj / grad_features must be non-null");
     if (desc->feat_layout == MVHMR_LAYOUT_QUAD) return fail(MVHMR_ERR_UNSUPPORTED, "backward takes planar or channels-last features");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     rc = check_ws(workspace, workspace_bytes, mvhmr_unproject_backward_workspace_bytes(desc));
@@ -338,6 +380,29 @@ int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_
     if (rc != MVHMR_OK || in_place) return rc;
     if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) return launched(launch_grad_to_planar(gradT, grad_features, p, s), "gradient layout pass");
     return launched(launch_grad_cast(gradT, grad_features, p, s), "gradient cast");
+}
+
+int mvhmr_unproject_backward(const mvhmr_unproject_desc *desc, const void *grad_out, const void *features, const float *proj,
+                             const float *coords, void *grad_features, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    Problem p;
+    int rc = check_desc(desc, &p);
+    if (rc != MVHMR_OK) return rc;
+    if (!coords) return fail(MVHMR_ERR_INVALID_ARGUMENT, "coords must be non-null");
+    return backward_impl(desc, p, grad_out, features, proj, coords_from_tensor(coords, p), grad_features, workspace, workspace_bytes, hip_stream);
+}
+
+int mvhmr_unproject_backward_cuboid(const mvhmr_unproject_desc *desc, const void *grad_out, const void *features, const float *proj,
+                                    const float *rot, const float *center, const double position[3], const double sides[3],
+                                    void *grad_features, void *workspace, size_t workspace_bytes, void *hip_stream)
+{
+    Problem p;
+    int rc = check_desc(desc, &p);
+    if (rc != MVHMR_OK) return rc;
+    Coords cs;
+    rc = coords_from_cuboid(rot, center, position, sides, p, &cs);
+    if (rc != MVHMR_OK) return rc;
+    return backward_impl(desc, p, grad_out, features, proj, cs, grad_features, workspace, workspace_bytes, hip_stream);
 }
 
 int mvhmr_preferred_layout(const mvhmr_unproject_desc *desc)

@@ -26,6 +26,26 @@ __device__ __forceinline__ bool gated_off(const Gate &g)
 }
 
 
+// voxel centre of (sample b, flat index n = (i*Y + j)*Z + k): tensor read or cuboid recipe (gate.h::Coords)
+__device__ __forceinline__ void voxel_xyz(const Coords &cs, int b, long long N, long long n, float &x, float &y, float &z)
+{
+    if (cs.ptr) {
+        const float *X = cs.ptr + ((long long)b * N + n) * 3;
+        x = X[0]; y = X[1]; z = X[2];
+        return;
+    }
+    const int k = (int)(n % cs.Z), j = (int)((n / cs.Z) % cs.Y), i = (int)(n / ((long long)cs.Y * cs.Z));
+    const float *R = cs.rot + b * 9, *ce = cs.center + b * 3;
+    // grid_coord = position + (sides / (S-1)) * grid   (fp32 mul then add, aggregation.py:157-159)
+    const float gx = __fadd_rn(cs.px, __fmul_rn(cs.sx, (float)i));
+    const float gy = __fadd_rn(cs.py, __fmul_rn(cs.sy, (float)j));
+    const float gz = __fadd_rn(cs.pz, __fmul_rn(cs.sz, (float)k));
+    const float dx = __fsub_rn(gx, ce[0]), dy = __fsub_rn(gy, ce[1]), dz = __fsub_rn(gz, ce[2]);             // :184
+    x = __fadd_rn(__fmaf_rn(R[2], dz, __fmaf_rn(R[1], dy, __fmul_rn(R[0], dx))), ce[0]);                    // :185-186, volumetric.py:110
+    y = __fadd_rn(__fmaf_rn(R[5], dz, __fmaf_rn(R[4], dy, __fmul_rn(R[3], dx))), ce[1]);
+    z = __fadd_rn(__fmaf_rn(R[8], dz, __fmaf_rn(R[7], dy, __fmul_rn(R[6], dx))), ce[2]);
+}
+
 enum : int { AGG_SOFTMAX = 0, AGG_SUM = 1, AGG_MEAN = 2, AGG_MAX = 3 };
 
 constexpr int kWave = 64;       // CDNA wavefront

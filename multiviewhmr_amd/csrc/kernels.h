@@ -39,9 +39,9 @@ hipError_t launch_grad_to_planar(const float *srcT, void *dst, const Problem &p,
 hipError_t launch_grad_cast(const float *srcT, void *dst, const Problem &p, hipStream_t s);
 
 // gather variant: featT is channels-last (B,V,HW,C4) in the feature dtype
-hipError_t launch_fwd_gather(const void *featT, const float *proj, const float *coords, void *out,
+hipError_t launch_fwd_gather(const void *featT, const float *proj, const Coords &coords, void *out,
                              const Problem &p, hipStream_t s);
-hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const float *proj, const float *coords,
+hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const float *proj, const Coords &coords,
                              float *gradT, const Problem &p, hipStream_t s);
 
 // brick variant (LDS-staged windows); launches return hipErrorNotSupported when the shape does not qualify.
@@ -52,7 +52,7 @@ bool brick_bwd_supported(const Problem &p);
 size_t brick_workspace_bytes(const Problem &p);
 hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, hipStream_t s);
 hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s);
-hipError_t launch_fwd_brick(const void *featK, const float *proj, const float *coords, void *out, const Problem &p,
+hipError_t launch_fwd_brick(const void *featK, const float *proj, const Coords &coords, void *out, const Problem &p,
                             hipStream_t s);
 
 // Geometry gate.  Counts the bricks whose pooled tap windows would not fit (from the projections of each brick's 8 corner
@@ -66,15 +66,15 @@ struct GateGeom {
 };
 GateGeom brick_fwd_gate_geom(const Problem &p);
 GateGeom brick_bwd_gate_geom(const Problem &p);
-hipError_t launch_brick_gate(const float *proj, const float *coords, int *count, const GateGeom &g, const Problem &p, hipStream_t s);
+hipError_t launch_brick_gate(const float *proj, const Coords &coords, int *count, const GateGeom &g, const Problem &p, hipStream_t s);
 int brick_count(const Problem &p, const GateGeom &g);
 
 // brick backward: featK quad-planar features, gradK zeroed fp32 quad-planar accumulator (same shape)
-hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK,
+hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const Coords &coords, float *gradK,
                             const Problem &p, hipStream_t s);
 hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Problem &p, hipStream_t s);
 
-hipError_t launch_build_coords(float *coords, const float *rot, const float *center, int B, int S,
+hipError_t launch_build_coords(float *coords_out, const float *rot, const float *center, int B, int S,
                                const double pos[3], const double sides[3], hipStream_t s);
 
 }  // namespace mvhmr

@@ -38,12 +38,11 @@ constexpr int bwd_cap_slots(int nt)
 // Slow path of k_bwd_brick for one voxel: global float atomics per tap (bricks whose windows do not fit the LDS pool).
 template <int METHOD, int VT, typename TO>
 __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const TO *gobase, float *gk, const float (*proj)[12],
-                                                         const float *Xp, unsigned vox, long long N, int nq, int H, int W)
+                                                         float c0, float c1, float c2, unsigned vox, long long N, int nq, int H, int W)
 {
     const int HW = H * W;
     float w00[VT], w01[VT], w10[VT], w11[VT];
     int o00[VT], o01[VT], o10[VT], o11[VT];
-    const float c0 = Xp[0], c1 = Xp[1], c2 = Xp[2];
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
         const Taps t = make_taps(proj[v], c0, c1, c2, H, W);
@@ -84,7 +83,7 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
 template <int METHOD, int VT, int NT, typename TO>
 __global__ void __launch_bounds__(NT)
 k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, const float *__restrict__ proj,
-            const float *__restrict__ coords, float *__restrict__ gradK, int C, int H, int W, int X, int Y, int Z, int nby,
+            const Coords coords, float *__restrict__ gradK, int C, int H, int W, int X, int Y, int Z, int nby,
             int nbz, int bricks_per_sample, int lds_bytes, int total_blocks, Gate gate)
 {
     if (gated_off(gate)) return;
@@ -116,9 +115,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     float w00[VT], w01[VT], w10[VT], w11[VT];
     int tx[VT], ty[VT];
     unsigned valid = 0;
+    float c0, c1, c2;
+    voxel_xyz(coords, b, N, vox, c0, c1, c2);
     {
-        const float *Xp = coords + ((long long)b * N + vox) * 3;
-        const float c0 = Xp[0], c1 = Xp[1], c2 = Xp[2];
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
@@ -380,7 +379,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     } else {
         // ---- windows do not fit: scatter straight to the accumulator (its own function: keeps its registers -- 16 tap
         // offsets on top of the weights -- out of the fast path's allocation, which otherwise spills in the quad loop)
-        bwd_brick_slow<METHOD, VT, TO>(fk, gobase, gk, sh->proj, coords + ((long long)b * N + vox) * 3, vox, N, nq, H, W);
+        bwd_brick_slow<METHOD, VT, TO>(fk, gobase, gk, sh->proj, c0, c1, c2, vox, N, nq, H, W);
     }
 }
 
@@ -404,7 +403,7 @@ constexpr int kNTb = 1024;                            // 2 / 4 views
 constexpr int kNTb8 = 512;                            // 8 views: 4 x 4 x 32 bricks, 256 VGPRs per lane, ONE feature window in LDS
 
 template <int METHOD, int VT, int NT, typename TO>
-hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
+hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj, const Coords &coords, float *gradK, const Problem &p,
                      hipStream_t s)
 {
     const int nbx = p.X / kBX, nby = p.Y / (NT / 128), nbz = p.Z / kBZ;
@@ -421,7 +420,7 @@ hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj,
 }
 
 template <int METHOD, typename TO>
-hipError_t launch_bm(const float4 *featK, const TO *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
+hipError_t launch_bm(const float4 *featK, const TO *grad_out, const float *proj, const Coords &coords, float *gradK, const Problem &p,
                      hipStream_t s)
 {
     switch (p.V) {
@@ -435,7 +434,7 @@ hipError_t launch_bm(const float4 *featK, const TO *grad_out, const float *proj,
 }
 
 template <typename TO>
-hipError_t launch_bt(const float4 *fk, const TO *go, const float *proj, const float *coords, float *gradK, const Problem &p, hipStream_t s)
+hipError_t launch_bt(const float4 *fk, const TO *go, const float *proj, const Coords &coords, float *gradK, const Problem &p, hipStream_t s)
 {
     switch (p.method) {
     case AGG_SOFTMAX: return launch_bm<AGG_SOFTMAX, TO>(fk, go, proj, coords, gradK, p, s);
@@ -448,7 +447,7 @@ hipError_t launch_bt(const float4 *fk, const TO *go, const float *proj, const fl
 }  // namespace
 
 // featK: quad-planar features; gradK: zeroed fp32 quad-planar accumulator of the same shape
-hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const float *coords, float *gradK, const Problem &p,
+hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const Coords &coords, float *gradK, const Problem &p,
                             hipStream_t s)
 {
     if (!brick_bwd_supported(p)) return hipErrorNotSupported;

@@ -151,7 +151,7 @@ int brick_count(const Problem &p, const GateGeom &g) { return (p.X / g.bx) * (p.
 // brick kernels would need (same arithmetic as their prologue: bbox + 2, odd line stride, 64-slot chunks).  Voxel centres are
 // affine in the index for every volume the caller builds, so the corners bound the brick's taps; only speed depends on it.
 __global__ void __launch_bounds__(256)
-k_brick_gate(const float *__restrict__ proj, const float *__restrict__ coords, int *__restrict__ count, int V, int H, int W, int X,
+k_brick_gate(const float *__restrict__ proj, const Coords coords, int *__restrict__ count, int V, int H, int W, int X,
              int Y, int Z, GateGeom g, int nbx, int nby, int nbz, int total)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -167,7 +167,8 @@ k_brick_gate(const float *__restrict__ proj, const float *__restrict__ coords, i
         bool front = true;
         for (int c = 0; c < 8; ++c) {
             const int vx = kx * g.bx + ((c & 1) ? g.bx - 1 : 0), vy = ky * g.by + ((c & 2) ? g.by - 1 : 0), vz = kz * kBZ + ((c & 4) ? kBZ - 1 : 0);
-            const float *Xp = coords + ((long long)b * N + ((long long)vx * Y + vy) * Z + vz) * 3;
+            float Xp[3];
+            voxel_xyz(coords, b, N, ((long long)vx * Y + vy) * Z + vz, Xp[0], Xp[1], Xp[2]);
             const float a = P[0] * Xp[0] + P[1] * Xp[1] + P[2] * Xp[2] + P[3];
             const float bb = P[4] * Xp[0] + P[5] * Xp[1] + P[6] * Xp[2] + P[7];
             const float z = P[8] * Xp[0] + P[9] * Xp[1] + P[10] * Xp[2] + P[11];
@@ -190,7 +191,7 @@ k_brick_gate(const float *__restrict__ proj, const float *__restrict__ coords, i
     if (!fits) atomicAdd(count, 1);
 }
 
-hipError_t launch_brick_gate(const float *proj, const float *coords, int *count, const GateGeom &g, const Problem &p, hipStream_t s)
+hipError_t launch_brick_gate(const float *proj, const Coords &coords, int *count, const GateGeom &g, const Problem &p, hipStream_t s)
 {
     const int nbx = p.X / g.bx, nby = p.Y / g.by, nbz = p.Z / kBZ, total = nbx * nby * nbz * p.B;
     hipLaunchKernelGGL(k_brick_gate, dim3((total + 255) / 256), dim3(256), 0, s, proj, coords, count, p.V, p.H, p.W, p.X, p.Y, p.Z, g,
@@ -199,13 +200,13 @@ hipError_t launch_brick_gate(const float *proj, const float *coords, int *count,
 }
 
 // ------------------------------------------------------------------------------------------------- dispatch
-extern template hipError_t launch_fwd_method<AGG_SOFTMAX>(const void *, const float *, const float *, void *, const Problem &, int, hipStream_t);
-extern template hipError_t launch_fwd_method<AGG_SUM>(const void *, const float *, const float *, void *, const Problem &, int, hipStream_t);
-extern template hipError_t launch_fwd_method<AGG_MEAN>(const void *, const float *, const float *, void *, const Problem &, int, hipStream_t);
-extern template hipError_t launch_fwd_method<AGG_MAX>(const void *, const float *, const float *, void *, const Problem &, int, hipStream_t);
+extern template hipError_t launch_fwd_method<AGG_SOFTMAX>(const void *, const float *, const Coords &, void *, const Problem &, int, hipStream_t);
+extern template hipError_t launch_fwd_method<AGG_SUM>(const void *, const float *, const Coords &, void *, const Problem &, int, hipStream_t);
+extern template hipError_t launch_fwd_method<AGG_MEAN>(const void *, const float *, const Coords &, void *, const Problem &, int, hipStream_t);
+extern template hipError_t launch_fwd_method<AGG_MAX>(const void *, const float *, const Coords &, void *, const Problem &, int, hipStream_t);
 
 // featK: column-major quad-planar fp32 copy of the features (launch_to_quad_planar_t)
-hipError_t launch_fwd_brick(const void *featK, const float *proj, const float *coords, void *out, const Problem &p, hipStream_t s)
+hipError_t launch_fwd_brick(const void *featK, const float *proj, const Coords &coords, void *out, const Problem &p, hipStream_t s)
 {
     if (!brick_fwd_supported(p)) return hipErrorNotSupported;
     const int nvox = brick_fwd_nvox(p);

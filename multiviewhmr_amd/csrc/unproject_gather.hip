@@ -27,15 +27,16 @@ struct alignas(16) TapRec {
 };
 
 __device__ __forceinline__ void build_records(TapRec *recs, const float *__restrict__ proj,
-                                              const float *__restrict__ coords, int b, int V, long long n0,
+                                              const Coords &coords, int b, int V, long long n0,
                                               long long N, int H, int W, int C4)
 {
     for (int idx = threadIdx.x; idx < kTileVox * V; idx += blockDim.x) {
         const int v = idx / kTileVox, j = idx % kTileVox;
         long long n = n0 + j;
         n = n < N ? n : N - 1;       // tail voxels are computed and dropped
-        const float *X = coords + ((long long)b * N + n) * 3;
-        const Taps t = make_taps(proj + ((long long)b * V + v) * 12, X[0], X[1], X[2], H, W);
+        float X0, X1, X2;
+        voxel_xyz(coords, b, N, n, X0, X1, X2);
+        const Taps t = make_taps(proj + ((long long)b * V + v) * 12, X0, X1, X2, H, W);
         TapRec r;
         r.o00 = (t.y0 * W + t.x0) * C4;
         r.o01 = (t.y0 * W + t.x1) * C4;
@@ -65,7 +66,7 @@ __device__ __forceinline__ UTap uniform_rec(const TapRec &r)
 // ------------------------------------------------------------------------------------------ forward
 template <typename TF, typename TO, int METHOD, int VT>
 __global__ void __launch_bounds__(256)
-k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const float *__restrict__ coords,
+k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const Coords coords,
              TO *__restrict__ out, int Vrt, int C, int C4, int H, int W, long long N, int tstride, Gate gate)
 {
     if (gated_off(gate)) return;
@@ -162,7 +163,7 @@ k_fwd_gather(const TF *__restrict__ featT, const float *__restrict__ proj, const
 template <typename TF, typename TO, int METHOD, int VT>
 __global__ void __launch_bounds__(256)
 k_bwd_gather(const TO *__restrict__ grad_out, const TF *__restrict__ featT, const float *__restrict__ proj,
-             const float *__restrict__ coords, float *__restrict__ gradT, int Vrt, int C, int C4, int H, int W,
+             const Coords coords, float *__restrict__ gradT, int Vrt, int C, int C4, int H, int W,
              long long N, Gate gate)
 {
     if (gated_off(gate)) return;
@@ -358,7 +359,7 @@ k_build_coords(float *__restrict__ coords, const float *__restrict__ rot, const 
 
 // ------------------------------------------------------------------------------------------ launchers
 template <typename TF, typename TO, int METHOD>
-static hipError_t fwd_dispatch_v(const TF *featT, const float *proj, const float *coords, TO *out, const Problem &p,
+static hipError_t fwd_dispatch_v(const TF *featT, const float *proj, const Coords &coords, TO *out, const Problem &p,
                                  hipStream_t s)
 {
     const int Q = p.C4 / 4;
@@ -382,7 +383,7 @@ static hipError_t fwd_dispatch_v(const TF *featT, const float *proj, const float
 }
 
 template <typename TF, typename TO>
-static hipError_t fwd_dispatch_m(const TF *featT, const float *proj, const float *coords, TO *out, const Problem &p,
+static hipError_t fwd_dispatch_m(const TF *featT, const float *proj, const Coords &coords, TO *out, const Problem &p,
                                  hipStream_t s)
 {
     switch (p.method) {
@@ -394,7 +395,7 @@ static hipError_t fwd_dispatch_m(const TF *featT, const float *proj, const float
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_fwd_gather(const void *featT, const float *proj, const float *coords, void *out, const Problem &p,
+hipError_t launch_fwd_gather(const void *featT, const float *proj, const Coords &coords, void *out, const Problem &p,
                              hipStream_t s)
 {
     if (!p.feat_f16 && !p.out_f16) return fwd_dispatch_m((const float *)featT, proj, coords, (float *)out, p, s);
@@ -404,7 +405,7 @@ hipError_t launch_fwd_gather(const void *featT, const float *proj, const float *
 }
 
 template <typename TF, typename TO, int METHOD>
-static hipError_t bwd_dispatch_v(const TO *go_, const TF *featT, const float *proj, const float *coords, float *gradT,
+static hipError_t bwd_dispatch_v(const TO *go_, const TF *featT, const float *proj, const Coords &coords, float *gradT,
                                  const Problem &p, hipStream_t s)
 {
     const size_t lds = sizeof(TapRec) * kTileVox * (size_t)p.V + sizeof(float) * kGroupCh * (kTileVox + 1);
@@ -425,7 +426,7 @@ static hipError_t bwd_dispatch_v(const TO *go_, const TF *featT, const float *pr
 }
 
 template <typename TF, typename TO>
-static hipError_t bwd_dispatch_m(const TO *go_, const TF *featT, const float *proj, const float *coords, float *gradT,
+static hipError_t bwd_dispatch_m(const TO *go_, const TF *featT, const float *proj, const Coords &coords, float *gradT,
                                  const Problem &p, hipStream_t s)
 {
     switch (p.method) {
@@ -437,7 +438,7 @@ static hipError_t bwd_dispatch_m(const TO *go_, const TF *featT, const float *pr
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const float *proj, const float *coords,
+hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const float *proj, const Coords &coords,
                              float *gradT, const Problem &p, hipStream_t s)
 {
     if (!p.feat_f16 && !p.out_f16) return bwd_dispatch_m((const float *)grad_out, (const float *)featT, proj, coords, gradT, p, s);

@@ -29,6 +29,19 @@ def get_rotation_matrix(axis, theta):
     return (w * w - v @ v) * np.eye(3) + 2.0 * np.outer(v, v) + 2.0 * w * skew
 
 
+def get_rotation_matrices(axis, thetas):
+    """get_rotation_matrix for an array of angles at once: (B,3,3) float64, entry for entry the same expressions."""
+    axis = np.asarray(axis, dtype=np.float64)
+    thetas = np.asarray(thetas, dtype=np.float64)
+    w = np.cos(thetas / 2.0)                                            # (B,)
+    v = -(axis / np.sqrt(axis @ axis))[None, :] * np.sin(thetas / 2.0)[:, None]     # (B,3)
+    zero = np.zeros_like(w)
+    skew = np.stack([np.stack([zero, v[:, 2], -v[:, 1]], -1), np.stack([-v[:, 2], zero, v[:, 0]], -1),
+                     np.stack([v[:, 1], -v[:, 0], zero], -1)], -2)
+    vv = np.einsum("bi,bi->b", v, v)
+    return (w * w - vv)[:, None, None] * np.eye(3)[None] + 2.0 * v[:, :, None] * v[:, None, :] + 2.0 * w[:, None, None] * skew
+
+
 def rotate_coord_volume(coord_volume, theta, axis):
     """Rotate every point of a (..., 3) coordinate volume about the origin; fp32 rotation like the reference."""
     rot = torch.from_numpy(get_rotation_matrix(axis, theta)).type(torch.float).to(coord_volume.device)

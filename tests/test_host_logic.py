@@ -206,3 +206,32 @@ def test_unprojection_has_no_cpu_fallback():
     f, p, c = _tiny()
     with pytest.raises(RuntimeError, match="no CPU path"):
         aggregation.unprojection(f, p, c)
+
+
+def test_batched_rotation_matrices_and_sized_theta_draws_match_the_per_sample_loop():
+    """VolumeGenerator.volume_pose draws all thetas with one sized call and builds the rotations vectorised: both must equal
+    the reference's per-sample loop (aggregation.py:163-167, volumetric.py:87-99), bit for bit"""
+    np.random.seed(123)
+    seq = np.array([np.random.uniform(0.0, 2 * np.pi) for _ in range(7)])
+    np.random.seed(123)
+    assert np.array_equal(seq, np.random.uniform(0.0, 2 * np.pi, size=7))
+    for axis in ([0, 0, 1], [0, 1, 0]):                                  # the two axes VolumeGenerator uses ('mpii' / 'coco'): bit-exact
+        batched = volumetric.get_rotation_matrices(axis, seq)
+        for b, th in enumerate(seq):
+            assert np.array_equal(batched[b], volumetric.get_rotation_matrix(axis, th))
+    batched = volumetric.get_rotation_matrices([1.0, 2.0, -0.5], seq)    # any other axis: same expressions, summation order of v.v may differ
+    for b, th in enumerate(seq):
+        assert np.abs(batched[b] - volumetric.get_rotation_matrix([1.0, 2.0, -0.5], th)).max() <= 4e-16
+    assert np.array_equal(volumetric.get_rotation_matrix([0, 0, 1], 0.0), np.eye(3))
+
+
+def test_device_projection_recipe_matches_the_host_one_on_cpu_tensors():
+    """feature_level_projections_device is plain torch float64 arithmetic: on CPU tensors it must reproduce the numpy path (and
+    hence the reference, test above) bit for bit -- the GPU runs the same IEEE operations"""
+    rng = np.random.default_rng(5)
+    V, B = 3, 4
+    cams = [[multiview.Camera(np.linalg.qr(rng.standard_normal((3, 3)))[0], rng.standard_normal((3, 1)) * 1000,
+                              np.array([[1100.0 + b, 0, 500 + v], [0, 1090.0 - v, 510 + b], [0, 0, 1.0]])) for b in range(B)] for v in range(V)]
+    host = aggregation.feature_level_projections(cams, (384, 320), (96, 80))
+    dev = aggregation.feature_level_projections_device(aggregation.pack_cameras(cams, "cpu"), (384, 320), (96, 80))
+    assert dev.dtype == torch.float32 and np.array_equal(dev.numpy(), host)

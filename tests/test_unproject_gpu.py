@@ -765,3 +765,48 @@ def test_dynamic_lds_opt_in_is_remembered_per_device_and_kernel():
             f, p, c = (torch.from_numpy(x).to(dev) for x in (feats, proj, coords))
             outs.append(aggregation.unprojection(f, p, c, variant="brick").cpu())
         assert torch.equal(outs[0], outs[1])
+
+
+# ------------------------------------------------------------------------------------ cuboid recipe evaluated in the kernels
+@pytest.mark.parametrize("variant", ("brick", "gather", "auto"))
+def test_cuboid_entry_is_bit_equal_to_the_coordinate_tensor_route(variant, gpu):
+    """mvhmr_unproject_*_cuboid evaluates rot @ (pos + step * ijk - center) + center per voxel with the rounding order of
+    mvhmr_build_coord_volumes: forward bit-equal, backward equal up to the order of the float atomics"""
+    B, V, C, H, S = 3, 4, 16, 32, 32
+    rng = np.random.default_rng(17)
+    feats, proj, _ = _ring_problem(B=B, V=V, C=C, H=H, W=H, vol=(S, S, S), seed=17)
+    gen = aggregation.VolumeGenerator(volume_size=S, input_channels=C, output_channels=C, device=gpu)
+    thetas = rng.uniform(0, 2 * np.pi, B)
+    from multiviewhmr_amd import volumetric
+    rots = torch.from_numpy(volumetric.get_rotation_matrices([0, 0, 1], thetas).astype(np.float32)).to(gpu)
+    centers = torch.from_numpy(rng.normal(0, 100, (B, 3)).astype(np.float32)).to(gpu)
+    coords = gen.coord_volumes(rots, centers, gpu)                              # mvhmr_build_coord_volumes
+    cub = gen.cuboid()
+    p = torch.from_numpy(proj).to(gpu)
+    fa = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    fb = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    a = aggregation.unprojection(fa, p, coords, variant=variant)
+    b = aggregation.unprojection_cuboid(fb, p, rots, centers, cub.position, cub.sides, (S, S, S), variant=variant)
+    assert torch.equal(a, b)
+    go = torch.randn_like(a)
+    a.backward(go); b.backward(go)
+    record_err("cuboid vs tensor route, bwd (%s)" % variant, float((fa.grad - fb.grad).abs().max()), 2e-5)
+    ref = cport.forward(feats, proj, coords.cpu().numpy(), "softmax")
+    record_err("cuboid route fwd vs oracle (%s)" % variant, _err(b.detach().cpu().numpy(), ref), TOL)
+
+
+def test_packed_cameras_give_the_same_volume_without_the_camera_loop(gpu):
+    d = load_golden("volgen", "train_mpii")
+    gen, batch, seed = _rebuild(d, gpu)
+    np.random.seed(seed)
+    with torch.no_grad():
+        a = gen(_dev(d, "features_in", gpu), _dev(d, "proj_org", gpu), batch)
+    packed = dict(batch)
+    packed["cameras_packed"] = aggregation.pack_cameras(batch["cameras"], gpu)
+    packed["keypoints_3d"] = torch.from_numpy(np.stack(batch["keypoints_3d"])).to(gpu)
+    del packed["cameras"]                                                        # never touched on this route
+    np.random.seed(seed)
+    with torch.no_grad():
+        b = gen(_dev(d, "features_in", gpu), _dev(d, "proj_org", gpu), packed)
+    assert torch.equal(a, b)
+    record_err("volgen volume train_mpii (packed cameras)", _err(b.cpu().numpy(), d["volume"]), TOL)
