@@ -164,6 +164,20 @@ int mvhmr_convert_features(const mvhmr_unproject_desc *desc, const void *feature
                            void *hip_stream);
 
 /*
+ * process_feature (the 1x1 conv in front of the un-projection, models/aggregation.py:108-110,189-191) fused with the layout pass:
+ *     y[m, co, p] = sum_ci weight[co, ci] * x[m, ci, p] + bias[co]          m = (b, v),  p = (y, x)
+ * computed as an fp32 MFMA GEMM whose epilogue writes dst in MVHMR_LAYOUT_QUAD (n_maps, c_out/4, Wf, Hf, 4) -- feed it to
+ * mvhmr_unproject_forward[_cuboid] with desc->feat_layout = MVHMR_LAYOUT_QUAD (brick variant) and the planar conv output and the
+ * layout pass never exist.  mvhmr_unproject_backward[_cuboid] accepts the same MVHMR_LAYOUT_QUAD features (brick backward) and
+ * then writes grad_features in the PLANAR layout (n_maps, c_out, Hf, Wf), which is what the conv's own backward consumes.
+ *   x (n_maps, c_in, Hf, Wf) fp32, weight (c_out, c_in) fp32 (nn.Conv2d's (c_out, c_in, 1, 1)), bias (c_out) fp32 or null.
+ * Shapes: c_in % 16 == 0, c_out % 128 == 0, Hf % 4 == 0, Wf % 32 == 0 (mvhmr_conv1x1_to_quad_supported), else MVHMR_ERR_UNSUPPORTED.
+ */
+int mvhmr_conv1x1_to_quad(const float *x, const float *weight, const float *bias, void *dst, int32_t n_maps, int32_t c_in,
+                          int32_t c_out, int32_t feat_h, int32_t feat_w, void *hip_stream);
+int mvhmr_conv1x1_to_quad_supported(int32_t c_in, int32_t c_out, int32_t feat_h, int32_t feat_w);
+
+/*
  * Caller-side helper of VolumeGenerator.forward (models/aggregation.py:138-187): fills
  * coords (B,S,S,S,3) fp32 with the cuboid grid `position + side/(S-1) * (i,j,k)` rotated by
  * rot[b] (3x3 row-major fp32, utils/volumetric.py:87-114) about center[b] (3 fp32):
@@ -186,6 +200,9 @@ int mvhmr_unproject_selected_variant(const mvhmr_unproject_desc *desc);
  */
 int mvhmr_unproject_query_variant(const mvhmr_unproject_desc *desc, const float *proj, const float *coords,
                                   void *hip_stream);
+int mvhmr_unproject_query_variant_cuboid(const mvhmr_unproject_desc *desc, const float *proj, const float *rot,
+                                         const float *center, const double position[3], const double sides[3],
+                                         void *hip_stream);
 
 /* Testing hook: the key under which the library remembers that it raised a kernel's dynamic-LDS limit (the attribute is
  * per device AND kernel; a second GPU driven from the same process must get its own opt-in). */

@@ -256,6 +256,59 @@ def feature_level_projections(cameras, images_shape, features_shape):
     return P.astype(np.float32)
 
 
+class _FusedAggregate(torch.autograd.Function):
+    """process_feature (1x1 conv) + un-projection with the conv output living only in the quad-planar layout the brick forward
+    stages (mvhmr_conv1x1_to_quad + mvhmr_unproject_forward_cuboid on MVHMR_LAYOUT_QUAD): the planar (B,V,C,Hf,Wf) conv output
+    and the layout pass over it are never written.  Backward: the brick backward gives the gradient w.r.t.
+    the conv output in the planar layout; weight / bias / input gradients are three GEMMs on it."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, proj, rot, center, position, sides, vol, method):
+        L = _capi.lib()
+        B, V, Cin, Hf, Wf = x.shape
+        Cout = weight.shape[0]
+        dev = x.device
+        x = x.contiguous()
+        w2 = weight.reshape(Cout, Cin).contiguous()
+        pos = (ctypes.c_double * 3)(*[float(v) for v in position])
+        sid = (ctypes.c_double * 3)(*[float(v) for v in sides])
+        with torch.cuda.device(dev):
+            quad = torch.empty(B * V * Cout * Hf * Wf, dtype=torch.float32, device=dev)
+            _capi.check(L.mvhmr_conv1x1_to_quad(_ptr(x), _ptr(w2), _ptr(bias) if bias is not None else ctypes.c_void_p(0), _ptr(quad),
+                                                B * V, Cin, Cout, Hf, Wf, _stream(dev)))
+            desc = _make_desc(torch.empty((B, V, Cout, Hf, Wf), dtype=torch.float32, device="meta"), vol, method, torch.float32, _capi.LAYOUT_QUAD, _capi.VARIANT["brick"])
+            out = torch.empty((B, Cout) + tuple(vol), dtype=torch.float32, device=dev)
+            _capi.check(L.mvhmr_unproject_forward_cuboid(ctypes.byref(desc), _ptr(quad), _ptr(proj), _ptr(rot), _ptr(center), pos, sid,
+                                                         _ptr(out), ctypes.c_void_p(0), 0, _stream(dev)))
+        ctx.save_for_backward(x, w2, quad, proj, rot, center)
+        ctx.desc, ctx.pos, ctx.sid, ctx.has_bias, ctx.wshape = desc, pos, sid, bias is not None, tuple(weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, w2, quad, proj, rot, center = ctx.saved_tensors
+        L = _capi.lib()
+        desc = ctx.desc
+        B, V, Cin, Hf, Wf = x.shape
+        Cout = w2.shape[0]
+        dev = x.device
+        grad_out = grad_out.contiguous()
+        with torch.cuda.device(dev):
+            gy = torch.empty((B * V, Cout, Hf * Wf), dtype=torch.float32, device=dev)           # gradient w.r.t. the conv output, planar
+            ws, wsp = _workspace(L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc)), dev)
+            _capi.check(L.mvhmr_unproject_backward_cuboid(ctypes.byref(desc), _ptr(grad_out), _ptr(quad), _ptr(proj), _ptr(rot), _ptr(center),
+                                                          ctx.pos, ctx.sid, _ptr(gy), wsp, 0 if ws is None else ws.numel(), _stream(dev)))
+        xf = x.view(B * V, Cin, Hf * Wf)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.matmul(w2.t(), gy).view(B, V, Cin, Hf, Wf)                              # (Cin, Cout) @ (BV, Cout, HW)
+        if ctx.needs_input_grad[1]:
+            gw = torch.einsum("nop,nip->oi", gy, xf).view(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = gy.sum(dim=(0, 2))
+        return gx, gw, gb, None, None, None, None, None, None, None
+
+
 def pack_cameras(cameras, device):
     """One pass over batch['cameras'] (list[V] of list[B] of Camera) -> float64 device tensors K (B,V,3,3) and Rt (B,V,3,4).
     A data loader that hands `batch['cameras_packed'] = pack_cameras(...)` (or builds the two tensors itself) lets
@@ -301,6 +354,8 @@ class VolumeGenerator(nn.Module):
         self.use_triangulation = use_triangulation
         self.kind = kind
         self.dataset = dataset
+        self.fused_conv = True            # 1x1 conv + layout pass as one MFMA GEMM where the brick kernels run (see _fused_path_applies)
+        self._fused_cache = {}
         self.to(device)
 
     # -- geometry the reference builds inside forward(); split out so it can be checked without a GPU
@@ -370,15 +425,50 @@ class VolumeGenerator(nn.Module):
         else:
             proj = torch.from_numpy(feature_level_projections(batch['cameras'], images_shape, features_shape)).to(device)
         rots, centers = self.volume_pose(batch, proj_org, images_shape)
+        cub = self.cuboid()
+        S = self.volume_size
+        rots, centers = rots.to(device), centers.to(device)
+
+        if self._fused_path_applies(features, proj, rots, centers, cub, S):
+            # 1x1 conv and layout pass in one MFMA GEMM, its output only ever exists in the layout the brick forward stages
+            conv = self.process_feature[0]
+            return _FusedAggregate.apply(features, conv.weight, conv.bias, proj.contiguous(), rots.to(torch.float32).contiguous(),
+                                         centers.to(torch.float32).contiguous(), tuple(cub.position), tuple(cub.sides), (S, S, S),
+                                         _capi.AGG[self.aggregation_method])
 
         features = features.view(-1, *features.shape[2:])
         features = self.process_feature(features)
         features = features.view(batch_size, n_views, *features.shape[1:])
         # the coordinate volumes (aggregation.py:138-187) are never materialised: the kernels evaluate the cuboid recipe per voxel
-        cub = self.cuboid()
-        S = self.volume_size
-        return unprojection_cuboid(features, proj, rots.to(device), centers.to(device), cub.position, cub.sides, (S, S, S),
+        return unprojection_cuboid(features, proj, rots, centers, cub.position, cub.sides, (S, S, S),
                                    aggregation_method=self.aggregation_method)
+
+    def _fused_path_applies(self, features, proj, rots, centers, cub, S):
+        """The fused conv writes the brick kernels' layout, so it is used only where the brick kernels run: fp32, shapes both
+        kernels take, and a geometry for which the device-side gate picks the brick variant.  That last question costs one
+        synchronous query the FIRST time a (volume, map, view, channel) shape is seen and is cached after that: the voxel pitch in
+        pixels is a property of the data set's camera rig and of the configuration, not of the batch."""
+        if not self.fused_conv or features.dtype != torch.float32 or not features.is_cuda or self.aggregation_method not in _METHODS:
+            return False
+        B, V, Cin, Hf, Wf = features.shape
+        conv = self.process_feature[0]
+        Cout = conv.out_channels
+        L = _capi.lib()
+        if not L.mvhmr_conv1x1_to_quad_supported(Cin, Cout, Hf, Wf):
+            return False
+        key = (S, Hf, Wf, V, Cout, self.aggregation_method, float(self.cuboid_side))
+        hit = self._fused_cache.get(key)
+        if hit is None:
+            meta = torch.empty((B, V, Cout, Hf, Wf), dtype=torch.float32, device="meta")
+            desc = _make_desc(meta, (S, S, S), _capi.AGG[self.aggregation_method], torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["auto"])
+            pos = (ctypes.c_double * 3)(*[float(v) for v in cub.position])
+            sid = (ctypes.c_double * 3)(*[float(v) for v in cub.sides])
+            with torch.cuda.device(features.device):
+                got = L.mvhmr_unproject_query_variant_cuboid(ctypes.byref(desc), _ptr(proj.contiguous()), _ptr(rots.to(torch.float32).contiguous()),
+                                                             _ptr(centers.to(torch.float32).contiguous()), pos, sid, _stream(features.device))
+            hit = got == _capi.VARIANT["brick"]
+            self._fused_cache[key] = hit
+        return hit
 
 
 def build_volume_generator(cfg):

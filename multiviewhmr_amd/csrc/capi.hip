@@ -114,7 +114,7 @@ bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->
 // (17 ms against 104 ms at the north-star size: profiles/r01_final_pmc.txt).  variant = gather keeps the gather backward.
 bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    return d->feat_layout == MVHMR_LAYOUT_BVCHW && d->variant != MVHMR_VARIANT_GATHER && brick_bwd_supported(p);
+    return (d->feat_layout == MVHMR_LAYOUT_BVCHW || d->feat_layout == MVHMR_LAYOUT_QUAD) && d->variant != MVHMR_VARIANT_GATHER && brick_bwd_supported(p);
 }
 
 // AUTO on planar input, for a shape both variants serve: the variant is chosen on the device from the geometry (gate.h).
@@ -328,7 +328,8 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
     int rc;
     if (!grad_out || !features || !proj || !grad_features)
         return fail(MVHMR_ERR_INVALID_ARGUMENT, "grad_out / features / proj / grad_features must be non-null");
-    if (desc->feat_layout == MVHMR_LAYOUT_QUAD) return fail(MVHMR_ERR_UNSUPPORTED, "backward takes planar or channels-last features");
+    if (desc->feat_layout == MVHMR_LAYOUT_QUAD && (!bwd_uses_brick(desc, p) || p.feat_f16))
+        return fail(MVHMR_ERR_UNSUPPORTED, "backward from quad-planar features needs the brick backward (fp32, one storage type, 2 / 4 / 8 views)");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     rc = check_ws(workspace, workspace_bytes, mvhmr_unproject_backward_workspace_bytes(desc));
     if (rc != MVHMR_OK) return rc;
@@ -356,7 +357,9 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
     }
     if (bwd_uses_brick(desc, p)) {
         float *gradK = reinterpret_cast<float *>(ws + brick_workspace_bytes(p));
-        rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
+        rc = desc->feat_layout == MVHMR_LAYOUT_QUAD
+                 ? launched(launch_quad_transpose(features, ws, p.B * p.V * (p.C / 4), p.H, p.W, s), "layout pass")   // column-major copy -> row-major
+                 : launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
         hipError_t e = hipMemsetAsync(gradK, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
         if (e != hipSuccess) return launched(e, "gradient clear");
@@ -442,6 +445,46 @@ int mvhmr_convert_features(const mvhmr_unproject_desc *desc, const void *feature
     if (dst_layout == MVHMR_LAYOUT_BVHWC) return launched(launch_to_channels_last(features, dst, p, s), "layout pass");
     if (dst_layout == MVHMR_LAYOUT_QUAD) return launched(launch_to_quad_planar_t(features, dst, p, s), "layout pass");
     return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown destination layout %d", dst_layout);
+}
+
+int mvhmr_conv1x1_to_quad(const float *x, const float *weight, const float *bias, void *dst, int32_t n_maps, int32_t c_in, int32_t c_out,
+                          int32_t feat_h, int32_t feat_w, void *hip_stream)
+{
+    if (!x || !weight || !dst) return fail(MVHMR_ERR_INVALID_ARGUMENT, "x / weight / dst must be non-null");
+    if (n_maps < 1 || c_in < 1 || c_out < 1 || feat_h < 1 || feat_w < 1) return fail(MVHMR_ERR_INVALID_ARGUMENT, "every dimension must be >= 1");
+    if (!conv1x1_quad_supported(c_in, c_out, feat_h, feat_w))
+        return fail(MVHMR_ERR_UNSUPPORTED, "fused 1x1 conv needs C_in %% 16 == 0, C_out %% 128 == 0, Hf %% 4 == 0, Wf %% 32 == 0 (got %d -> %d, %dx%d)",
+                    c_in, c_out, feat_h, feat_w);
+    return launched(launch_conv1x1_quad(x, weight, bias, dst, n_maps, c_in, c_out, feat_h, feat_w, static_cast<hipStream_t>(hip_stream)),
+                    "fused 1x1 conv");
+}
+
+int mvhmr_conv1x1_to_quad_supported(int32_t c_in, int32_t c_out, int32_t feat_h, int32_t feat_w)
+{
+    return conv1x1_quad_supported(c_in, c_out, feat_h, feat_w) ? 1 : 0;
+}
+
+int mvhmr_unproject_query_variant_cuboid(const mvhmr_unproject_desc *desc, const float *proj, const float *rot, const float *center,
+                                         const double position[3], const double sides[3], void *hip_stream)
+{
+    Problem p;
+    if (check_desc(desc, &p) != MVHMR_OK) return -1;
+    const int variant = pick_variant(desc, p);
+    if (variant_conflict(desc, p, variant) != MVHMR_OK) return -1;
+    if (desc->variant != MVHMR_VARIANT_AUTO || !brick_fwd_supported(p)) return variant;
+    Coords cs;
+    if (!proj || coords_from_cuboid(rot, center, position, sides, p, &cs) != MVHMR_OK) { fail(MVHMR_ERR_INVALID_ARGUMENT, "null pointer"); return -1; }
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    int *count = nullptr, host = 0;
+    if (hipMalloc(&count, sizeof(int)) != hipSuccess) { fail(MVHMR_ERR_LAUNCH, "query: allocation failed"); return -1; }
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int), s);
+    const GateGeom g = brick_fwd_gate_geom(p);
+    if (e == hipSuccess) e = launch_brick_gate(proj, cs, count, g, p, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(&host, count, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(count);
+    if (e != hipSuccess) { fail(MVHMR_ERR_LAUNCH, "query: %s", hipGetErrorString(e)); return -1; }
+    return host <= brick_count(p, g) / 8 ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
 }
 
 int mvhmr_build_coord_volumes(float *coords, const float *rot, const float *center, int32_t batch, int32_t volume_size,

@@ -1,0 +1,157 @@
+// process_feature fused with the layout pass (reference models/aggregation.py:108-110,189-191):
+//     y[bv, co, p] = sum_ci W[co, ci] * x[bv, ci, p] + bias[co]
+// as an fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32: exact fp32 FMA chains at the vector rate, MI355X_MICROARCH.md) whose epilogue
+// writes the COLUMN-major quad-planar copy (B,V,Cout/4,Wf,Hf,4) that the brick forward stages -- the (B,V,Cout,Hf,Wf) tensor
+// the reference's nn.Conv2d produces, and the layout pass over it, never exist.
+//
+// Mapping (CDNA4, wave64).  Block = 256 threads, output tile = 128 channels x 128 pixels (4 image rows x 32 columns); the four
+// waves own 64 x 64 sub-tiles = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers per lane).  K (= Cin) is staged through LDS
+// in chunks of 16, double-buffered: A = W tile [128][16] (row stride 17: conflict-free fragment reads), B = x tile [16][4 rows]
+// [32 + 8 pad] (the pad makes the (row, column) -> MFMA column map below conflict-free).  Pixel j of a 32-wide MFMA tile is
+// (row j % 4, column j / 4) of an 8-column strip, so that the four lanes j .. j+3 hold four consecutive ROWS of one image column:
+// in the column-major destination they are 64 contiguous bytes, one TCP access per lane quad.
+// The 32x32x2 accumulator layout gives every lane 4 consecutive output channels of one pixel per register group: exactly one
+// 16-B slot of the quad-planar layout, so the epilogue is four float4 stores per MFMA tile, no shuffles.
+#include "device_common.h"
+#include "kernels.h"
+
+namespace mvhmr {
+
+namespace {
+constexpr int kTM = 128, kTN = 128, kTK = 16;
+constexpr int kLdA = kTK + 1;                  // 17: lanes of a fragment read (consecutive rows) hit distinct banks
+constexpr int kRowB = 32 + 8;                  // image-row stride inside a k-row of B: bank = 8 * (j % 4) + j / 4, all 32 distinct
+constexpr int kLdB = 4 * kRowB;                // 160 floats per k
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+}  // namespace
+
+// requires Cin % 16 == 0, Cout % 128 == 0, H % 4 == 0, W % 32 == 0 (checked by the launcher)
+__global__ void __launch_bounds__(256)
+k_conv1x1_quad(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, float4 *__restrict__ dst,
+               int Cin, int Cout, int H, int W)
+{
+    __shared__ float sA[2][kTM * kLdA];
+    __shared__ float sB[2][kTK * kLdB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_x = W >> 5;
+    const int x0 = (blockIdx.x % tiles_x) << 5, y0 = (blockIdx.x / tiles_x) << 2;
+    const int m0 = blockIdx.y * kTM;
+    const long long bv = blockIdx.z;
+    const long long HW = (long long)H * W;
+    const float *xb = x + bv * Cin * HW;
+
+    // global -> LDS assignments: A: thread t loads W[m0 + t/2][k0 + 8*(t%2) .. +8]; B: thread t loads x[k0 + t/16][y0 + (t%16)/4][x0 + 8*(t%4) .. +8]
+    const int a_row = tid >> 1, a_k = (tid & 1) << 3;
+    const int b_k = tid >> 4, b_y = (tid & 15) >> 2, b_x = (tid & 3) << 3;
+    const float *ga = w + (long long)(m0 + a_row) * Cin + a_k;
+    const float *gb = xb + (long long)b_k * HW + (long long)(y0 + b_y) * W + x0 + b_x;
+    float4 ra[2], rb[2];
+    auto gload = [&](int k0) {
+        ra[0] = *reinterpret_cast<const float4 *>(ga + k0); ra[1] = *reinterpret_cast<const float4 *>(ga + k0 + 4);
+        const float *p = gb + (long long)k0 * HW;
+        rb[0] = *reinterpret_cast<const float4 *>(p); rb[1] = *reinterpret_cast<const float4 *>(p + 4);
+    };
+    auto lstore = [&](int buf) {
+        float *a = &sA[buf][a_row * kLdA + a_k];
+        a[0] = ra[0].x; a[1] = ra[0].y; a[2] = ra[0].z; a[3] = ra[0].w; a[4] = ra[1].x; a[5] = ra[1].y; a[6] = ra[1].z; a[7] = ra[1].w;
+        float *b = &sB[buf][b_k * kLdB + b_y * kRowB + b_x];
+        *reinterpret_cast<float4 *>(b) = rb[0];
+        *reinterpret_cast<float4 *>(b + 4) = rb[1];
+    };
+
+    // this wave's 64 x 64 sub-tile: rows wm .. wm+63 of the block tile, MFMA column tiles 2*wn, 2*wn+1 (8 image columns each)
+    const int wm = (wave >> 1) << 6, wn = (wave & 1) << 1;
+    const int fi = lane & 31, fk = lane >> 5;                                    // fragment row / column index, k within the pair
+    const int pj = (fi & 3) * kRowB + (fi >> 2);                                 // LDS offset of MFMA column fi inside a strip: (row fi%4, column fi/4)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int nk = Cin / kTK;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) gload((kc + 1) * kTK);                                   // next chunk in flight under the MFMAs
+        const float *A = sA[buf], *Bm = sB[buf];
+#pragma unroll
+        for (int k = 0; k < kTK; k += 2) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = A[(wm + 32 * i + fi) * kLdA + k + fk];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = Bm[(k + fk) * kLdB + (wn + j) * 8 + pj];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (kc + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: accumulator register r of lane (fi, fk) is output row 8*(r/4) + 4*fk + r%4, column fi of the MFMA tile
+    const int Q = Cout >> 2;
+    const int py = y0 + (fi & 3);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int px = x0 + (wn + j) * 8 + (fi >> 2);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = m0 + wm + 32 * i + 8 * g + 4 * fk;               // first of 4 consecutive channels
+                float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                if (bias) { const float4 bq = *reinterpret_cast<const float4 *>(bias + co); o.x += bq.x; o.y += bq.y; o.z += bq.z; o.w += bq.w; }
+                dst[(bv * Q + (co >> 2)) * HW + (long long)px * H + py] = o;
+            }
+        }
+}
+
+bool conv1x1_quad_supported(int Cin, int Cout, int H, int W) { return Cin % kTK == 0 && Cout % kTM == 0 && H % 4 == 0 && W % 32 == 0; }
+
+hipError_t launch_conv1x1_quad(const float *x, const float *w, const float *bias, void *dst, int BV, int Cin, int Cout, int H, int W,
+                               hipStream_t s)
+{
+    if (!conv1x1_quad_supported(Cin, Cout, H, W)) return hipErrorNotSupported;
+    const dim3 grid((W / 32) * (H / 4), Cout / kTM, BV);
+    hipLaunchKernelGGL(k_conv1x1_quad, grid, dim3(256), 0, s, x, w, bias, (float4 *)dst, Cin, Cout, H, W);
+    return hipGetLastError();
+}
+
+// column-major quad-planar (BV, C/4, W, H, 4) -> row-major quad-planar (BV, C/4, H, W, 4): what the brick backward stages, when the
+// forward kept only the fused copy.  32 x 32 pixel tiles through LDS, 512-B runs both ways.
+__global__ void __launch_bounds__(256)
+k_quad_transpose(const float4 *__restrict__ src, float4 *__restrict__ dst, int H, int W)
+{
+    __shared__ float4 tile[32][33];
+    const long long plane = (long long)blockIdx.z * H * W;
+    const int tiles_x = (W + 31) >> 5;
+    const int x0 = (blockIdx.x % tiles_x) << 5, y0 = (blockIdx.x / tiles_x) << 5;
+    const int t0 = threadIdx.x & 31, t1 = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int xx = t1 + 8 * i, x = x0 + xx, y = y0 + t0;                     // lanes along y: contiguous in the source
+        if (x < W && y < H) tile[xx][t0] = src[plane + (long long)x * H + y];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int yy = t1 + 8 * i, y = y0 + yy, x = x0 + t0;                     // lanes along x: contiguous in the destination
+        if (x < W && y < H) dst[plane + (long long)y * W + x] = tile[t0][yy];
+    }
+}
+
+hipError_t launch_quad_transpose(const void *src, void *dst, int planes, int H, int W, hipStream_t s)
+{
+    const dim3 grid(((W + 31) / 32) * ((H + 31) / 32), 1, planes);
+    hipLaunchKernelGGL(k_quad_transpose, grid, dim3(256), 0, s, (const float4 *)src, (float4 *)dst, H, W);
+    return hipGetLastError();
+}
+
+}  // namespace mvhmr

@@ -74,6 +74,13 @@ hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float
                             const Problem &p, hipStream_t s);
 hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Problem &p, hipStream_t s);
 
+// process_feature fused with the layout pass: y = W x + b as an fp32 MFMA GEMM writing the column-major quad-planar copy
+bool conv1x1_quad_supported(int Cin, int Cout, int H, int W);
+hipError_t launch_conv1x1_quad(const float *x, const float *w, const float *bias, void *dst, int BV, int Cin, int Cout, int H, int W,
+                               hipStream_t s);
+// column-major quad-planar -> row-major quad-planar (planes = B * V * C / 4)
+hipError_t launch_quad_transpose(const void *src, void *dst, int planes, int H, int W, hipStream_t s);
+
 hipError_t launch_build_coords(float *coords_out, const float *rot, const float *center, int B, int S,
                                const double pos[3], const double sides[3], hipStream_t s);
 

@@ -1,5 +1,5 @@
-"""End-to-end VolumeGenerator.forward (the caller of the hot path: camera bookkeeping on the host, coord volumes on the
-device, 1x1 conv, un-projection) at the north-star shape, with a synthetic `batch` dict.  SURVEY.md 8(d)/(f) row 1."""
+"""End-to-end VolumeGenerator.forward (the caller of the hot path) at the north-star shape with a synthetic `batch` dict:
+host geometry, 1x1 conv, un-projection -- per route."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,22 +18,33 @@ for v in range(V):
         cams[v][b] = multiview.Camera(R, t, K)
 batch = {"images": np.zeros((B, V, IMG, IMG, 3), np.uint8), "cameras": cams,
          "keypoints_3d": [rng.normal(0, 100, (17, 3)).astype(np.float32) for _ in range(B)]}
+packed = dict(batch)
+packed["cameras_packed"] = aggregation.pack_cameras(cams, dev)
+packed["keypoints_3d"] = torch.from_numpy(np.stack(batch["keypoints_3d"])).to(dev)
 gen = aggregation.VolumeGenerator(volume_size=S, input_channels=C, output_channels=C, device=dev).eval()
 feats = torch.randn(B, V, C, H, H, device=dev)
 proj_org = torch.from_numpy(np.stack([[cams[v][b].projection for v in range(V)] for b in range(B)]).astype(np.float32)).to(dev)
+
+
+def timed(fn, n=8):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
 with torch.no_grad():
-    for it in range(6):
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+    def geometry():
         proj = torch.from_numpy(aggregation.feature_level_projections(batch["cameras"], (IMG, IMG), (H, H))).to(dev)
-        rots, centers = gen.volume_pose(batch, proj_org, (IMG, IMG))
-        coords = gen.coord_volumes(rots, centers, dev)
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        f2 = gen.process_feature(feats.view(-1, C, H, H)).view(B, V, C, H, H)
-        torch.cuda.synchronize(); t2 = time.perf_counter()
-        vol = aggregation.unprojection(f2, proj, coords)
-        torch.cuda.synchronize(); t3 = time.perf_counter()
-        vol2 = gen(feats, proj_org, batch)
-        torch.cuda.synchronize(); t4 = time.perf_counter()
-        if it >= 2:
-            print("geometry (host cameras + device coord volumes) %.2f ms | 1x1 conv %.2f ms | unprojection %.2f ms | forward() total %.2f ms"
-                  % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
+        return proj, gen.volume_pose(batch, proj_org, (IMG, IMG))
+    def geometry_packed():
+        proj = aggregation.feature_level_projections_device(packed["cameras_packed"], (IMG, IMG), (H, H))
+        return proj, gen.volume_pose(packed, proj_org, (IMG, IMG))
+    print("host geometry: camera objects %.3f ms | packed cameras on the device %.3f ms" % (timed(geometry), timed(geometry_packed)))
+    print("1x1 conv (nn.Conv2d / MIOpen) %.2f ms" % timed(lambda: gen.process_feature(feats.view(-1, C, H, H))))
+    for fused in (False, True):
+        gen.fused_conv = fused
+        for name, bt in (("camera objects", batch), ("packed cameras", packed)):
+            print("VolumeGenerator.forward, %s, %-14s: %.2f ms" % ("fused 1x1 conv + layout" if fused else "nn.Conv2d + layout pass  ", name,
+                                                                   timed(lambda: gen(feats, proj_org, bt))))

@@ -810,3 +810,73 @@ def test_packed_cameras_give_the_same_volume_without_the_camera_loop(gpu):
         b = gen(_dev(d, "features_in", gpu), _dev(d, "proj_org", gpu), packed)
     assert torch.equal(a, b)
     record_err("volgen volume train_mpii (packed cameras)", _err(b.cpu().numpy(), d["volume"]), TOL)
+
+
+# ------------------------------------------------------------------------------------ 1x1 conv fused with the layout pass
+def test_conv1x1_to_quad_matches_conv2d_and_the_layout_pass(gpu):
+    """mvhmr_conv1x1_to_quad (fp32 MFMA GEMM, epilogue in MVHMR_LAYOUT_QUAD) == nn.Conv2d followed by mvhmr_convert_features"""
+    L = _capi.lib()
+    torch.manual_seed(3)
+    BV, Cin, Cout, H, W = 6, 48, 256, 20, 64
+    x = torch.randn(BV, Cin, H, W, device=gpu)
+    conv = torch.nn.Conv2d(Cin, Cout, 1).to(gpu)
+    with torch.no_grad():
+        y = conv(x).contiguous()                                                  # (BV, Cout, H, W)
+    vp = ctypes.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    assert L.mvhmr_conv1x1_to_quad_supported(Cin, Cout, H, W) == 1 and L.mvhmr_conv1x1_to_quad_supported(Cin, Cout, H, 40) == 0
+    quad = torch.empty(BV * Cout * H * W, device=gpu)
+    w2 = conv.weight.detach().reshape(Cout, Cin).contiguous()
+    _capi.check(L.mvhmr_conv1x1_to_quad(vp(x.data_ptr()), vp(w2.data_ptr()), vp(conv.bias.data_ptr()), vp(quad.data_ptr()), BV, Cin, Cout, H, W, stream))
+    ref = y.view(BV, Cout // 4, 4, H, W).permute(0, 1, 4, 3, 2).contiguous()     # (BV, C/4, W, H, 4)
+    record_err("fused 1x1 conv vs nn.Conv2d", float((quad.view_as(ref) - ref).abs().max()), 2e-5 * float(ref.abs().max()) + 1e-6)
+    # and the layout pass proper gives the same memory image from the planar conv output
+    desc = aggregation._make_desc(y.view(1, BV, Cout, H, W), (4, 8, 32), 0, torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["brick"])
+    conv_copy = torch.empty(L.mvhmr_feature_layout_bytes(ctypes.byref(desc), _capi.LAYOUT_QUAD) // 4, device=gpu)
+    _capi.check(L.mvhmr_convert_features(ctypes.byref(desc), vp(y.data_ptr()), _capi.LAYOUT_QUAD, vp(conv_copy.data_ptr()), stream))
+    assert torch.equal(conv_copy[: ref.numel()].view_as(ref), ref)
+
+
+@pytest.mark.parametrize("training", (False, True))
+def test_volume_generator_fused_path_equals_the_unfused_one(training, gpu):
+    """VolumeGenerator with the fused conv (default where the brick kernels run) against the same module with fused_conv off:
+    volume, and in training the gradients of the input features, the conv weight and its bias"""
+    B, V, C, H, S, IMG = 2, 4, 128, 32, 32, 128
+    rng = np.random.default_rng(61)
+    cams = [[None] * B for _ in range(V)]
+    for v in range(V):
+        az = 2 * np.pi * v / V + 0.3
+        eye = np.array([5000 * np.cos(az), 5000 * np.sin(az), 1500.0])
+        fwd = -eye / np.linalg.norm(eye)
+        right = np.cross(fwd, [0, 0, 1.0]); right /= np.linalg.norm(right)
+        R = np.stack([right, np.cross(fwd, right), fwd])
+        for b in range(B):
+            cam = multiview.Camera(R, -R @ eye, [[1145.0, 0, 512], [0, 1145.0, 512], [0, 0, 1]])
+            cam.update_after_crop((150, 150, 850, 850))
+            cam.update_after_resize((700, 700), (IMG, IMG))
+            cams[v][b] = cam
+    batch = dict(images=np.zeros((B, V, IMG, IMG, 3), np.uint8), cameras=cams,
+                 keypoints_3d=[rng.normal(0, 100, (17, 3)).astype(np.float32) for _ in range(B)])
+    proj_org = torch.from_numpy(np.stack([[cams[v][b].projection for v in range(V)] for b in range(B)]).astype(np.float32)).to(gpu)
+    torch.manual_seed(9)
+    gen = aggregation.VolumeGenerator(volume_size=S, input_channels=C, output_channels=C, device=gpu).train(training)
+    x = torch.randn(B, V, C, H, H, device=gpu)
+    outs, grads = {}, {}
+    for fused in (True, False):
+        gen.fused_conv = fused
+        gen.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(training)
+        np.random.seed(77)
+        with torch.set_grad_enabled(training):
+            vol = gen(xi, proj_org, batch)
+        outs[fused] = vol.detach()
+        if training:
+            go = torch.randn(vol.shape, device=gpu, generator=torch.Generator(device=gpu).manual_seed(5))
+            vol.backward(go)
+            grads[fused] = (xi.grad.clone(), gen.process_feature[0].weight.grad.clone(), gen.process_feature[0].bias.grad.clone())
+    assert gen._fused_cache and all(gen._fused_cache.values())                      # the fused path really ran
+    scale = float(outs[False].abs().max())
+    record_err("fused vs unfused volume (training=%s)" % training, float((outs[True] - outs[False]).abs().max()), 2e-5 * scale + 1e-6)
+    if training:
+        for name, a, b in zip(("input", "weight", "bias"), grads[True], grads[False]):
+            record_err("fused vs unfused grad %s" % name, float((a - b).abs().max()), 1e-4 * max(1.0, float(b.abs().max())))
