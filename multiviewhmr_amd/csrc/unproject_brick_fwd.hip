@@ -124,7 +124,9 @@ size_t brick_workspace_bytes(const Problem &p)
 // ------------------------------------------------------------------------------------------------- brick geometry
 int fwd_lds_slots() { return (160 * 1024 - 1024) / 16; }
 static int fwd_threads(int V) { return V == 8 ? 512 : 1024; }          // 8 views: 256 VGPRs per lane
-int brick_fwd_nvox(const Problem &p) { return p.X % (2 * kBX) == 0 ? 2 : 1; }   // 8 x 8 x 32 bricks when x allows, else 4 x 8 x 32
+// 8 x 8 x 32 bricks (two voxels per lane) when x allows; 8 views keep 4 x 4 x 32: their eight windows of a doubled brick (mean
+// ~4 300 slots, max ~6 000 at the configs[3] geometry) overflow the 2-deep ring (4 928) for most bricks
+int brick_fwd_nvox(const Problem &p) { return (p.V <= 4 && p.X % (2 * kBX) == 0) ? 2 : 1; }
 
 bool brick_fwd_supported(const Problem &p)
 {

@@ -529,7 +529,12 @@ def test_config3_eight_views_per_gpu_shard(gpu):
     c = torch.from_numpy(coords).to(gpu).expand(B, -1, -1, -1, -1).contiguous()
     out = aggregation.unprojection(f, p, c)
     err, _ = _oracle_on_channels(f, p, c, out, [0, 200, 255], b=15)
-    assert err <= TOL
+    record_err("configs[3] shard fwd (sample 15, 3 channels)", err, TOL)
+    # the geometry gate must keep this shard on the brick kernels (a doubled 8-view brick would overflow the LDS windows)
+    L = _capi.lib()
+    desc = aggregation._make_desc(f, c, _capi.AGG["softmax"], torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["auto"])
+    assert L.mvhmr_unproject_query_variant(ctypes.byref(desc), ctypes.c_void_p(p.data_ptr()), ctypes.c_void_p(c.data_ptr()),
+                                           ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == _capi.VARIANT["brick"]
     mean = aggregation.unprojection(f, p, c, aggregation_method="mean")
     s = aggregation.unprojection(f, p, c, aggregation_method="sum")
     assert float((mean - s / V).abs().max()) <= 1e-6
