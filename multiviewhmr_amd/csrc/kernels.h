@@ -59,7 +59,7 @@ hipError_t launch_fwd_brick(const void *featK, const float *proj, const Coords &
 // voxels; speed heuristic only) into *count (zeroed by the caller).  GateGeom describes the bricks and windows of the kernel
 // the gate decides for.
 struct GateGeom {
-    int bx, by;          // brick extent in x and y (z is always 32)
+    int bx, by, bz;      // brick extent in voxels
     int column_major;    // window lines run along y (forward) or x (backward)
     int cap_slots;       // 16-B LDS slots one window set may use
     int max_chunks;      // 64-slot DMA chunks a block can issue per quad

@@ -26,6 +26,9 @@ namespace mvhmr {
 //   feature buffer = kZeroBytes of zeros + cap 16-B slots (as in the forward)
 //   gradient plane = (kZeroSlots + cap) floats; the first kZeroSlots only ever receive +0 (samples that are identically zero)
 constexpr int kBwdLdsBytes = 160 * 1024 - 1024;
+// brick shapes: 4 x (threads / 128) x 32 voxels (128-B grad_out runs per wave half), or 8 x 8 x 16 for 1024 threads (64-B runs, but a
+// third fewer window pixels per voxel at ~1.3 px per voxel: the flush and the window DMA shrink with it)
+constexpr int bwd_brick_x(int bz) { return bz == 32 ? kBX : 8; }
 // 1024-thread bricks (2 / 4 views) keep two feature windows in LDS (the next quad's is prefetched); the 512-thread bricks of
 // 8 views need the room for their windows (mean 3 300, max 4 600 slots at the configs[3] geometry) and keep one
 constexpr int bwd_feature_buffers(int nt) { return nt >= 1024 ? 2 : 1; }
@@ -80,14 +83,15 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
     }
 }
 
-template <int METHOD, int VT, int NT, typename TO>
+template <int METHOD, int VT, int NT, typename TO, int BZ>
 __global__ void __launch_bounds__(NT)
 k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, const float *__restrict__ proj,
             const Coords coords, float *__restrict__ gradK, int C, int H, int W, int X, int Y, int Z, int nby,
             int nbz, int bricks_per_sample, int lds_bytes, int total_blocks, Gate gate)
 {
     if (gated_off(gate)) return;
-    constexpr int BY = NT / 128, NW = NT / 64;
+    // brick = BX x BY x BZ voxels, one per lane; a wave holds 64 / BZ whole z columns
+    constexpr int BX = bwd_brick_x(BZ), BY = NT / (BZ * BX), NW = NT / 64, CW = 64 / BZ;
     constexpr int MC = brick_chunks_per_wave(NT);
     constexpr int NBUF = bwd_feature_buffers(NT);                                // feature windows in LDS: 2 (next quad prefetched) or 1
     extern __shared__ __align__(16) unsigned char smem[];
@@ -107,10 +111,14 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     __syncthreads();
 
     // ---- this lane's voxel and its tap records (identical to the forward)
-    const int col = wave * 2 + (lane >> 5);
+    // ds_read_b128 serves the lanes {0-3, 12-15, 20-27} of each wave half in one pass and the other 16 in the next: z32 renumbers a
+    // half so that a pass holds 16 consecutive z (of one column: distinct window rows, odd row stride -> distinct bank groups)
     const int l5 = lane & 31;
-    const int zin = l5 < 4 ? l5 : l5 < 12 ? 12 + l5 : l5 < 16 ? l5 - 8 : l5 < 20 ? 8 + l5 : l5 < 28 ? l5 - 12 : l5;
-    const int vx = kx * kBX + (col & 3), vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
+    const int z32 = l5 < 4 ? l5 : l5 < 12 ? 12 + l5 : l5 < 16 ? l5 - 8 : l5 < 20 ? 8 + l5 : l5 < 28 ? l5 - 12 : l5;
+    const int kq = (lane >> 5) * 2 + (z32 >> 4);                                  // which of the wave's four columns (BZ == 16)
+    const int col = BZ == 32 ? wave * 2 + (lane >> 5) : ((wave >> 2) + 4 * (kq >> 1)) * BX + (wave & 3) + 4 * (kq & 1);
+    const int zin = z32 % BZ;
+    const int vx = kx * BX + col % BX, vy = ky * BY + col / BX, vz = kz * BZ + zin;
     const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);
     float w00[VT], w01[VT], w10[VT], w11[VT];
     int tx[VT], ty[VT];
@@ -402,15 +410,23 @@ namespace {
 constexpr int kNTb = 1024;                            // 2 / 4 views
 constexpr int kNTb8 = 512;                            // 8 views: 4 x 4 x 32 bricks, 256 VGPRs per lane, ONE feature window in LDS
 
-template <int METHOD, int VT, int NT, typename TO>
+// z extent of the bricks: 8 x 8 x 16 for fp32 storage with 2 / 4 views when the volume divides (fp16 grad_out would come in 32-B
+// runs), 4 x BY x 32 otherwise
+int bwd_brick_z(const Problem &p)
+{
+    return (!p.out_f16 && p.V <= 4 && p.X % 8 == 0 && p.Y % 8 == 0 && p.Z % 16 == 0) ? 16 : kBZ;
+}
+
+template <int METHOD, int VT, int NT, typename TO, int BZ = kBZ>
 hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj, const Coords &coords, float *gradK, const Problem &p,
                      hipStream_t s)
 {
-    const int nbx = p.X / kBX, nby = p.Y / (NT / 128), nbz = p.Z / kBZ;
+    constexpr int BX = bwd_brick_x(BZ), BY = NT / (BZ * BX);
+    const int nbx = p.X / BX, nby = p.Y / BY, nbz = p.Z / BZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
     const int lds_bytes = kBwdLdsBytes;
     const size_t lds = (size_t)lds_bytes + sizeof(BrickShared<VT>);
-    auto kern = k_bwd_brick<METHOD, VT, NT, TO>;
+    auto kern = k_bwd_brick<METHOD, VT, NT, TO, BZ>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const int grid = ((bps + 7) / 8) * 8 * p.B;
@@ -424,8 +440,14 @@ hipError_t launch_bm(const float4 *featK, const TO *grad_out, const float *proj,
                      hipStream_t s)
 {
     switch (p.V) {
-    case 2: return launch_bv<METHOD, 2, kNTb, TO>(featK, grad_out, proj, coords, gradK, p, s);
-    case 4: return launch_bv<METHOD, 4, kNTb, TO>(featK, grad_out, proj, coords, gradK, p, s);
+    case 2:
+        if constexpr (sizeof(TO) == 4)
+            if (bwd_brick_z(p) == 16) return launch_bv<METHOD, 2, kNTb, TO, 16>(featK, grad_out, proj, coords, gradK, p, s);
+        return launch_bv<METHOD, 2, kNTb, TO>(featK, grad_out, proj, coords, gradK, p, s);
+    case 4:
+        if constexpr (sizeof(TO) == 4)
+            if (bwd_brick_z(p) == 16) return launch_bv<METHOD, 4, kNTb, TO, 16>(featK, grad_out, proj, coords, gradK, p, s);
+        return launch_bv<METHOD, 4, kNTb, TO>(featK, grad_out, proj, coords, gradK, p, s);
     case 8:
         if constexpr (sizeof(TO) == 4) return launch_bv<METHOD, 8, kNTb8, TO>(featK, grad_out, proj, coords, gradK, p, s);
         break;
@@ -472,7 +494,8 @@ bool brick_bwd_supported(const Problem &p)
     if (p.V != 2 && p.V != 4 && p.V != 8) return false;
     if (p.V == 8 && p.out_f16) return false;
     const int nt = p.V == 8 ? kNTb8 : kNTb;
-    if (p.C % 4 || p.Z % kBZ || p.X % kBX || p.Y % (nt / 128)) return false;
+    if (p.C % 4) return false;
+    if (bwd_brick_z(p) != 16 && (p.Z % kBZ || p.X % kBX || p.Y % (nt / 128))) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
     if (p.N >= (1ll << 28)) return false;
     return true;
@@ -482,7 +505,8 @@ GateGeom brick_bwd_gate_geom(const Problem &p)
 {
     const int nt = p.V == 8 ? kNTb8 : kNTb;
     GateGeom g;
-    g.bx = kBX; g.by = nt / 128; g.column_major = 0;
+    g.bz = bwd_brick_z(p);
+    g.bx = bwd_brick_x(g.bz); g.by = nt / (g.bz * g.bx); g.column_major = 0;
     g.cap_slots = bwd_cap_slots(nt);
     g.max_chunks = brick_chunks_per_wave(nt) * (nt / 64);
     return g;

@@ -141,13 +141,13 @@ GateGeom brick_fwd_gate_geom(const Problem &p)
 {
     const int nt = fwd_threads(p.V);
     GateGeom g;
-    g.bx = kBX * brick_fwd_nvox(p); g.by = nt / 128; g.column_major = 1;
+    g.bx = kBX * brick_fwd_nvox(p); g.by = nt / 128; g.bz = kBZ; g.column_major = 1;
     g.cap_slots = fwd_cap2(fwd_lds_slots());                              // the 2-deep ring still stages through LDS
     g.max_chunks = brick_chunks_per_wave(nt) * (nt / 64);
     return g;
 }
 
-int brick_count(const Problem &p, const GateGeom &g) { return (p.X / g.bx) * (p.Y / g.by) * (p.Z / kBZ) * p.B; }
+int brick_count(const Problem &p, const GateGeom &g) { return (p.X / g.bx) * (p.Y / g.by) * (p.Z / g.bz) * p.B; }
 
 // ---- geometry gate: one thread per brick projects the brick's 8 corner voxels into every view and sizes the pooled windows the
 // brick kernels would need (same arithmetic as their prologue: bbox + 2, odd line stride, 64-slot chunks).  Voxel centres are
@@ -168,7 +168,7 @@ k_brick_gate(const float *__restrict__ proj, const Coords coords, int *__restric
         float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
         bool front = true;
         for (int c = 0; c < 8; ++c) {
-            const int vx = kx * g.bx + ((c & 1) ? g.bx - 1 : 0), vy = ky * g.by + ((c & 2) ? g.by - 1 : 0), vz = kz * kBZ + ((c & 4) ? kBZ - 1 : 0);
+            const int vx = kx * g.bx + ((c & 1) ? g.bx - 1 : 0), vy = ky * g.by + ((c & 2) ? g.by - 1 : 0), vz = kz * g.bz + ((c & 4) ? g.bz - 1 : 0);
             float Xp[3];
             voxel_xyz(coords, b, N, ((long long)vx * Y + vy) * Z + vz, Xp[0], Xp[1], Xp[2]);
             const float a = P[0] * Xp[0] + P[1] * Xp[1] + P[2] * Xp[2] + P[3];
@@ -195,7 +195,7 @@ k_brick_gate(const float *__restrict__ proj, const Coords coords, int *__restric
 
 hipError_t launch_brick_gate(const float *proj, const Coords &coords, int *count, const GateGeom &g, const Problem &p, hipStream_t s)
 {
-    const int nbx = p.X / g.bx, nby = p.Y / g.by, nbz = p.Z / kBZ, total = nbx * nby * nbz * p.B;
+    const int nbx = p.X / g.bx, nby = p.Y / g.by, nbz = p.Z / g.bz, total = nbx * nby * nbz * p.B;
     hipLaunchKernelGGL(k_brick_gate, dim3((total + 255) / 256), dim3(256), 0, s, proj, coords, count, p.V, p.H, p.W, p.X, p.Y, p.Z, g,
                        nbx, nby, nbz, total);
     return hipGetLastError();
