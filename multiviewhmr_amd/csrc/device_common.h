@@ -189,8 +189,9 @@ __device__ __forceinline__ void aggregate_grad(const float (&s)[V], float g, flo
         }
         const float rden = __builtin_amdgcn_rcpf(den);
         const float o = num * rden, gr = g * rden;
+        const float c0 = gr - gr * o;
 #pragma unroll
-        for (int v = 0; v < V; ++v) ds[v] = gr * e[v] * (1.f + s[v] - o);   // g * p_v * (1 + s_v - out)
+        for (int v = 0; v < V; ++v) ds[v] = e[v] * fmaf(gr, s[v], c0);      // g * p_v * (1 + s_v - out)
     }
 }
 
