@@ -29,13 +29,13 @@ constexpr int kBwdLdsBytes = 160 * 1024 - 1024;
 // brick shapes: 4 x (threads / 128) x 32 voxels (128-B grad_out runs per wave half), or 8 x 8 x 16 for 1024 threads (64-B runs, but a
 // third fewer window pixels per voxel at ~1.3 px per voxel: the flush and the window DMA shrink with it)
 constexpr int bwd_brick_x(int bz) { return bz == 32 ? kBX : 8; }
-// 1024-thread bricks (2 / 4 views) keep two feature windows in LDS (the next quad's is prefetched); the 512-thread bricks of
-// 8 views need the room for their windows (mean 3 300, max 4 600 slots at the configs[3] geometry) and keep one
-constexpr int bwd_feature_buffers(int nt) { return nt >= 1024 ? 2 : 1; }
+// two feature windows in LDS (the next quad's is prefetched) -- except for the 4 x 4 x 32 bricks of 8 views, which need the room for
+// their windows (mean 3 300, max 4 600 slots at the configs[3] geometry; 8 x 4 x 16: 2 450 / 3 072) and keep one
+constexpr int bwd_feature_buffers(int nt, int bz) { return (nt >= 1024 || bz == 16) ? 2 : 1; }
 // slots per window set: NBUF * (kZeroBytes + 16 cap) + 4 planes * 4 B * (kZeroSlots + cap) <= kBwdLdsBytes
-constexpr int bwd_cap_slots(int nt)
+constexpr int bwd_cap_slots(int nt, int bz)
 {
-    return ((kBwdLdsBytes - bwd_feature_buffers(nt) * kZeroBytes - 16 * kZeroSlots) / (16 * bwd_feature_buffers(nt) + 16)) & ~63;
+    return ((kBwdLdsBytes - bwd_feature_buffers(nt, bz) * kZeroBytes - 16 * kZeroSlots) / (16 * bwd_feature_buffers(nt, bz) + 16)) & ~63;
 }
 
 // Slow path of k_bwd_brick for one voxel: global float atomics per tap (bricks whose windows do not fit the LDS pool).
@@ -93,7 +93,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     // brick = BX x BY x BZ voxels, one per lane; a wave holds 64 / BZ whole z columns
     constexpr int BX = bwd_brick_x(BZ), BY = NT / (BZ * BX), NW = NT / 64, CW = 64 / BZ;
     constexpr int MC = brick_chunks_per_wave(NT);
-    constexpr int NBUF = bwd_feature_buffers(NT);                                // feature windows in LDS: 2 (next quad prefetched) or 1
+    constexpr int NBUF = bwd_feature_buffers(NT, BZ);                               // feature windows in LDS: 2 (next quad prefetched) or 1
     extern __shared__ __align__(16) unsigned char smem[];
     BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_bytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
@@ -116,7 +116,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     const int l5 = lane & 31;
     const int z32 = l5 < 4 ? l5 : l5 < 12 ? 12 + l5 : l5 < 16 ? l5 - 8 : l5 < 20 ? 8 + l5 : l5 < 28 ? l5 - 12 : l5;
     const int kq = (lane >> 5) * 2 + (z32 >> 4);                                  // which of the wave's four columns (BZ == 16)
-    const int col = BZ == 32 ? wave * 2 + (lane >> 5) : ((wave >> 2) + 4 * (kq >> 1)) * BX + (wave & 3) + 4 * (kq & 1);
+    const int col = BZ == 32 ? wave * 2 + (lane >> 5) : ((wave >> 2) + (BY / 2) * (kq >> 1)) * BX + (wave & 3) + 4 * (kq & 1);
     const int zin = z32 % BZ;
     const int vx = kx * BX + col % BX, vy = ky * BY + col / BX, vz = kz * BZ + zin;
     const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);
@@ -162,7 +162,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     }
     // capacity (bwd_cap_slots): compile-time, so that the plane and
     // buffer strides fold into the immediate offsets of the ds_ instructions (run-time strides cost 32 address registers)
-    constexpr int cap = bwd_cap_slots(NT);
+    constexpr int cap = bwd_cap_slots(NT, BZ);
     constexpr int buf_bytes = kZeroBytes + cap * 16;
     constexpr int plane_floats = kZeroSlots + cap;
     int *const iplanes = reinterpret_cast<int *>(smem + NBUF * buf_bytes);
@@ -410,11 +410,12 @@ namespace {
 constexpr int kNTb = 1024;                            // 2 / 4 views
 constexpr int kNTb8 = 512;                            // 8 views: 4 x 4 x 32 bricks, 256 VGPRs per lane, ONE feature window in LDS
 
-// z extent of the bricks: 8 x 8 x 16 for 2 / 4 views when the volume divides (fp16 grad_out then comes in 32-B runs: still hidden,
-// 18.1 -> 15.1 ms like fp32), 4 x BY x 32 otherwise
+// z extent of the bricks: 8 x 8 x 16 (2 / 4 views) or 8 x 4 x 16 (8 views) when the volume divides (fp16 grad_out then comes in
+// 32-B runs: still hidden, 18.1 -> 15.1 ms like fp32), 4 x BY x 32 otherwise
 int bwd_brick_z(const Problem &p)
 {
-    return (p.V <= 4 && p.X % 8 == 0 && p.Y % 8 == 0 && p.Z % 16 == 0) ? 16 : kBZ;
+    const int by = p.V == 8 ? 4 : 8;
+    return (p.X % 8 == 0 && p.Y % by == 0 && p.Z % 16 == 0) ? 16 : kBZ;
 }
 
 template <int METHOD, int VT, int NT, typename TO, int BZ = kBZ>
@@ -447,7 +448,10 @@ hipError_t launch_bm(const float4 *featK, const TO *grad_out, const float *proj,
         if (bwd_brick_z(p) == 16) return launch_bv<METHOD, 4, kNTb, TO, 16>(featK, grad_out, proj, coords, gradK, p, s);
         return launch_bv<METHOD, 4, kNTb, TO>(featK, grad_out, proj, coords, gradK, p, s);
     case 8:
-        if constexpr (sizeof(TO) == 4) return launch_bv<METHOD, 8, kNTb8, TO>(featK, grad_out, proj, coords, gradK, p, s);
+        if constexpr (sizeof(TO) == 4) {
+            if (bwd_brick_z(p) == 16) return launch_bv<METHOD, 8, kNTb8, TO, 16>(featK, grad_out, proj, coords, gradK, p, s);
+            return launch_bv<METHOD, 8, kNTb8, TO>(featK, grad_out, proj, coords, gradK, p, s);
+        }
         break;
     }
     return hipErrorNotSupported;
@@ -505,7 +509,7 @@ GateGeom brick_bwd_gate_geom(const Problem &p)
     GateGeom g;
     g.bz = bwd_brick_z(p);
     g.bx = bwd_brick_x(g.bz); g.by = nt / (g.bz * g.bx); g.column_major = 0;
-    g.cap_slots = bwd_cap_slots(nt);
+    g.cap_slots = bwd_cap_slots(nt, g.bz);
     g.max_chunks = brick_chunks_per_wave(nt) * (nt / 64);
     return g;
 }
