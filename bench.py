@@ -175,6 +175,7 @@ def train_step_bench(a, rank, world, dev, use_rccl):
     feats = torch.randn(B, V, Cin, HW, HW, device=dev, requires_grad=True)
     proj_org = torch.from_numpy(np.stack([[cams[v][b].projection for v in range(V)] for b in range(B)]).astype(np.float32)).to(dev)
     n_grad = sum(p.numel() for p in gen.parameters())
+    grad_vol = torch.randn(B, C, S, S, S, device=dev) * (1.0 / (B * C * S ** 3))
 
     def sync():
         torch.cuda.synchronize()
@@ -190,7 +191,8 @@ def train_step_bench(a, rank, world, dev, use_rccl):
         t = [time.perf_counter()]
         vol = gen(feats, proj_org, batch)
         if record: torch.cuda.synchronize(); t.append(time.perf_counter())
-        vol.mean().backward()     # a loss without full-volume temporaries (the real consumer is the 3-D regressor)
+        vol.backward(grad_vol)    # the consumer (the 3-D regressor) hands back a dense gradient; a scalar loss here would time torch's
+                                  # 8.6 GB reduce + broadcast copy (6.7 ms at this size) instead of the aggregator
         if record: torch.cuda.synchronize(); t.append(time.perf_counter())
         if world > 1:
             sharding.allreduce_aggregator_grads(gen)
@@ -222,7 +224,7 @@ def train_step_bench(a, rank, world, dev, use_rccl):
         "config": {"workload": "VolumeGenerator train step: %d^3 grid, %d views, 1x1 conv %d->%d ch, %dx%d maps, batch %d per GPU, softmax"
                                % (S, V, Cin, C, HW, HW, B), "global_batch": B * world,
                    "parallelism": "batch-sharded x%d; flat all-reduce of %d fp32 conv gradients" % (world, n_grad)},
-        "phases_ms": {"forward": round(parts[0] / 2 * 1e3, 2), "loss_backward": round(parts[1] / 2 * 1e3, 2),
+        "phases_ms": {"forward": round(parts[0] / 2 * 1e3, 2), "backward": round(parts[1] / 2 * 1e3, 2),
                       "grad_allreduce": round(parts[2] / 2 * 1e3, 3)},
     }
     if world > 1:
