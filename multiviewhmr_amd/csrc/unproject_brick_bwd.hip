@@ -283,27 +283,23 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        auto jacobian = [&](int q) {                                             // ds of quad q from its samples and gn; max |ds| published
-            float g[4];
+        // ds of channel i of quad q from its samples and gn[i]; the block-wide max |ds| is published for the quad's scale
+        auto jacobian1 = [&](int q, int i) __attribute__((always_inline)) {
+            aggregate_grad<METHOD, VT>(s[i], gn[i], ds[i]);
+            // max |ds| on the BITS (sign cleared): non-negative floats order as ints, and Inf / NaN (>= 0x7f800000) sort above
+            // every finite value instead of being dropped as fmaxf drops a NaN -- a non-finite gradient must stay visible
+            int big = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) g[i] = gn[i];
-            if (q + 1 < nq) load_g(q + 1);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                aggregate_grad<METHOD, VT>(s[i], g[i], ds[i]);
-                // max |ds| on the BITS (sign cleared): non-negative floats order as ints, and Inf / NaN (>= 0x7f800000) sort above
-                // every finite value instead of being dropped as fmaxf drops a NaN -- a non-finite gradient must stay visible
-                int big = 0;
-#pragma unroll
-                for (int v = 0; v < VT; ++v) { const int a = __builtin_bit_cast(int, ds[i][v]) & 0x7fffffff; big = a > big ? a : big; }
-                const int bb = wave_max_dpp(big);
-                if (lane == 0) atomicMax(&sh->aux[(q & 1) * 4 + i], bb);            // one scale per channel of the quad
-            }
+            for (int v = 0; v < VT; ++v) { const int a = __builtin_bit_cast(int, ds[i][v]) & 0x7fffffff; big = a > big ? a : big; }
+            const int bb = wave_max_dpp(big);
+            if (lane == 0) atomicMax(&sh->aux[(q & 1) * 4 + i], bb);                // one scale per channel of the quad
         };
         if (NBUF == 2 && nq > 1) dma(1);
         resample(0);
         if (NBUF == 1 && nq > 1) { lds_barrier(); dma(1); }                      // single buffer: every wave has sampled window 0
-        jacobian(0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) jacobian1(0, i);
+        if (nq > 1) load_g(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // window 1 has landed
         lds_barrier();
 #pragma nounroll
@@ -330,33 +326,39 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 // of the pixels the reference's float scatter would poison, so that isfinite() checks downstream still trip.
                 if (bbits >= 0x7f800000) { scale[i] = 0.f; inv_scale[i] = __builtin_nanf(""); }
             }
-#pragma unroll
-            for (int v = 0; v < VT; ++v) {
-                // two address registers per view (tap row 0 / row 1); planes and the +1 column are immediate offsets.
-                // Opaque to the optimiser: hoisted out of the loop they become 32 pinned registers and the kernel spills
-                int r0 = ga[v] * 4;
-                asm volatile("" : "+v"(r0));
-                const int r1 = r0 + ws[v] * 4;
-                // lanes whose sample is identically zero add nothing: parked on the zero slot they would all hit ONE
-                // address, and same-address LDS atomics serialise (2 cycles per lane)
-                if ((valid >> v) & 1u)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float d = ds[i][v] * scale[i];
-                    int *p0 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r0);
-                    int *p1 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r1);
-                    lds_add(p0, round_int(d * w00[v]));
-                    lds_add(p0 + 1, round_int(d * w01[v]));
-                    lds_add(p1, round_int(d * w10[v]));
-                    lds_add(p1 + 1, round_int(d * w11[v]));
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
             if (q + 2 < nq) {
                 if (NBUF == 1) lds_barrier();                                    // single buffer: every wave has sampled window q+1
                 dma(q + 2);                                                      // into the buffer quad q (or q+1) was sampled from
             }
-            if (q + 1 < nq) jacobian(q + 1);
+            // channel by channel: the 16 adds of quad q (fire and forget: the LDS unit retires ~14.5 lane-adds per clock, so a wave
+            // issues them at the pace of the whole CU's queue), then the Jacobian of quad q+1 for the same channel (VALU only; it
+            // overwrites ds[i], which the adds just issued have read) -- the arithmetic runs while the queue drains
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int v = 0; v < VT; ++v) {
+                    // two address registers (tap row 0 / row 1); planes and the +1 column are immediate offsets.
+                    // Opaque to the optimiser: hoisted out of the loop they become pinned registers and the kernel spills
+                    int r0 = ga[v] * 4;
+                    asm volatile("" : "+v"(r0));
+                    const int r1 = r0 + ws[v] * 4;
+                    // lanes whose sample is identically zero add nothing: parked on the zero slot they would all hit ONE
+                    // address, and same-address LDS atomics serialise (2 cycles per lane)
+                    if ((valid >> v) & 1u) {
+                        const float d = ds[i][v] * scale[i];
+                        int *p0 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r0);
+                        int *p1 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r1);
+                        lds_add(p0, round_int(d * w00[v]));
+                        lds_add(p0 + 1, round_int(d * w01[v]));
+                        lds_add(p1, round_int(d * w10[v]));
+                        lds_add(p1 + 1, round_int(d * w11[v]));
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < nq) jacobian1(q + 1, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q + 2 < nq) load_g(q + 2);
             lds_barrier();                                                       // adds of quad q landed; max of quad q+1 published
             // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction
             float *gq = gk + (long long)q * HW * 4;
