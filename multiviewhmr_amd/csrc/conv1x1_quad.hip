@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 }  // namespace
 
 // requires Cin % 16 == 0, Cout % 128 == 0, H % 4 == 0, W % 32 == 0 (checked by the launcher)
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_conv1x1_quad(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, float4 *__restrict__ dst,
                int Cin, int Cout, int H, int W)
 {
@@ -45,18 +45,18 @@ k_conv1x1_quad(const float *__restrict__ x, const float *__restrict__ w, const f
     const int b_k = tid >> 4, b_y = (tid & 15) >> 2, b_x = (tid & 3) << 3;
     const float *ga = w + (long long)(m0 + a_row) * Cin + a_k;
     const float *gb = xb + (long long)b_k * HW + (long long)(y0 + b_y) * W + x0 + b_x;
-    float4 ra[2], rb[2];
-    auto gload = [&](int k0) {
-        ra[0] = *reinterpret_cast<const float4 *>(ga + k0); ra[1] = *reinterpret_cast<const float4 *>(ga + k0 + 4);
+    float4 ra0, ra1, rb0, rb1;                                                   // scalars, not arrays: they must stay in registers
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+        ra0 = *reinterpret_cast<const float4 *>(ga + k0); ra1 = *reinterpret_cast<const float4 *>(ga + k0 + 4);
         const float *p = gb + (long long)k0 * HW;
-        rb[0] = *reinterpret_cast<const float4 *>(p); rb[1] = *reinterpret_cast<const float4 *>(p + 4);
+        rb0 = *reinterpret_cast<const float4 *>(p); rb1 = *reinterpret_cast<const float4 *>(p + 4);
     };
-    auto lstore = [&](int buf) {
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
         float *a = &sA[buf][a_row * kLdA + a_k];
-        a[0] = ra[0].x; a[1] = ra[0].y; a[2] = ra[0].z; a[3] = ra[0].w; a[4] = ra[1].x; a[5] = ra[1].y; a[6] = ra[1].z; a[7] = ra[1].w;
+        a[0] = ra0.x; a[1] = ra0.y; a[2] = ra0.z; a[3] = ra0.w; a[4] = ra1.x; a[5] = ra1.y; a[6] = ra1.z; a[7] = ra1.w;
         float *b = &sB[buf][b_k * kLdB + b_y * kRowB + b_x];
-        *reinterpret_cast<float4 *>(b) = rb[0];
-        *reinterpret_cast<float4 *>(b + 4) = rb[1];
+        *reinterpret_cast<float4 *>(b) = rb0;
+        *reinterpret_cast<float4 *>(b + 4) = rb1;
     };
 
     // this wave's 64 x 64 sub-tile: rows wm .. wm+63 of the block tile, MFMA column tiles 2*wn, 2*wn+1 (8 image columns each)
