@@ -178,6 +178,16 @@ int mvhmr_conv1x1_to_quad(const float *x, const float *weight, const float *bias
 int mvhmr_conv1x1_to_quad_supported(int32_t c_in, int32_t c_out, int32_t feat_h, int32_t feat_w);
 
 /*
+ * The same fp32 MFMA GEMM with a planar result: dst (n_maps, c_out, pixels) = weight (c_out, c_in) @ x (n_maps, c_in, pixels)
+ * (+ bias).  With the transposed weight it is the gradient w.r.t. the input of process_feature (autograd through
+ * models/aggregation.py:189-191), which the Python binding's fused route uses in backward.
+ * Shapes: c_in % 16 == 0, c_out % 128 == 0, pixels % 128 == 0 (mvhmr_conv1x1_planar_supported), else MVHMR_ERR_UNSUPPORTED.
+ */
+int mvhmr_conv1x1_planar(const float *x, const float *weight, const float *bias, float *dst, int32_t n_maps, int32_t c_in,
+                         int32_t c_out, int32_t pixels, void *hip_stream);
+int mvhmr_conv1x1_planar_supported(int32_t c_in, int32_t c_out, int32_t pixels);
+
+/*
  * Caller-side helper of VolumeGenerator.forward (models/aggregation.py:138-187): fills
  * coords (B,S,S,S,3) fp32 with the cuboid grid `position + side/(S-1) * (i,j,k)` rotated by
  * rot[b] (3x3 row-major fp32, utils/volumetric.py:87-114) about center[b] (3 fp32):

@@ -301,7 +301,13 @@ class _FusedAggregate(torch.autograd.Function):
         xf = x.view(B * V, Cin, Hf * Wf)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = torch.matmul(w2.t(), gy).view(B, V, Cin, Hf, Wf)                              # (Cin, Cout) @ (BV, Cout, HW)
+            if L.mvhmr_conv1x1_planar_supported(Cout, Cin, Hf * Wf):                           # (Cin, Cout) @ (BV, Cout, HW) on the MFMA GEMM
+                gx = torch.empty((B, V, Cin, Hf, Wf), dtype=torch.float32, device=dev)
+                wt = w2.t().contiguous()
+                with torch.cuda.device(dev):
+                    _capi.check(L.mvhmr_conv1x1_planar(_ptr(gy), _ptr(wt), ctypes.c_void_p(0), _ptr(gx), B * V, Cout, Cin, Hf * Wf, _stream(dev)))
+            else:
+                gx = torch.matmul(w2.t(), gy).view(B, V, Cin, Hf, Wf)
         if ctx.needs_input_grad[1]:
             gw = torch.einsum("nop,nip->oi", gy, xf).view(ctx.wshape)
         if ctx.has_bias and ctx.needs_input_grad[2]:

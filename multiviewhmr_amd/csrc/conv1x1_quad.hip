@@ -25,7 +25,12 @@ constexpr int kLdB = 4 * kRowB;                // 160 floats per k
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 }  // namespace
 
-// requires Cin % 16 == 0, Cout % 128 == 0, H % 4 == 0, W % 32 == 0 (checked by the launcher)
+// QUAD_OUT = false is the same GEMM with a planar result (BV, Cout, H*W): the tile is 128 consecutive pixels of the flattened map (MFMA
+// column j = pixel j), the epilogue writes 128-B runs per channel.  Used for the gradient w.r.t. the conv input (weights transposed
+// by the caller), where hipBLASLt's batched pick runs at half this kernel's rate.
+// requires Cin % 16 == 0, Cout % 128 == 0 and (QUAD_OUT: H % 4 == 0, W % 32 == 0; planar: H * W % 128 == 0) (checked by the launchers).
+// Pinned to 4 waves per SIMD (accumulators in VGPRs, 102 registers): at 3 the MFMA pipe is 65 % busy, at 4 ~82 %.
+template <bool QUAD_OUT>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
 k_conv1x1_quad(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias, float4 *__restrict__ dst,
                int Cin, int Cout, int H, int W)
@@ -34,7 +39,8 @@ k_conv1x1_quad(const float *__restrict__ x, const float *__restrict__ w, const f
     __shared__ float sB[2][kTK * kLdB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_x = W >> 5;
-    const int x0 = (blockIdx.x % tiles_x) << 5, y0 = (blockIdx.x / tiles_x) << 2;
+    const int x0 = QUAD_OUT ? (blockIdx.x % tiles_x) << 5 : 0, y0 = QUAD_OUT ? (blockIdx.x / tiles_x) << 2 : 0;
+    const int p0 = blockIdx.x * kTN;                                             // planar form: first pixel of the tile
     const int m0 = blockIdx.y * kTM;
     const long long bv = blockIdx.z;
     const long long HW = (long long)H * W;
@@ -44,7 +50,9 @@ k_conv1x1_quad(const float *__restrict__ x, const float *__restrict__ w, const f
     const int a_row = tid >> 1, a_k = (tid & 1) << 3;
     const int b_k = tid >> 4, b_y = (tid & 15) >> 2, b_x = (tid & 3) << 3;
     const float *ga = w + (long long)(m0 + a_row) * Cin + a_k;
-    const float *gb = xb + (long long)b_k * HW + (long long)(y0 + b_y) * W + x0 + b_x;
+    // (planar form: the same thread -> LDS map with "image row" b_y = 32-pixel segment b_y of the tile)
+    const float *gb = QUAD_OUT ? xb + (long long)b_k * HW + (long long)(y0 + b_y) * W + x0 + b_x
+                               : xb + (long long)b_k * HW + p0 + b_y * 32 + b_x;
     float4 ra0, ra1, rb0, rb1;                                                   // scalars, not arrays: they must stay in registers
     auto gload = [&](int k0) __attribute__((always_inline)) {
         ra0 = *reinterpret_cast<const float4 *>(ga + k0); ra1 = *reinterpret_cast<const float4 *>(ga + k0 + 4);
@@ -62,7 +70,9 @@ k_conv1x1_quad(const float *__restrict__ x, const float *__restrict__ w, const f
     // this wave's 64 x 64 sub-tile: rows wm .. wm+63 of the block tile, MFMA column tiles 2*wn, 2*wn+1 (8 image columns each)
     const int wm = (wave >> 1) << 6, wn = (wave & 1) << 1;
     const int fi = lane & 31, fk = lane >> 5;                                    // fragment row / column index, k within the pair
-    const int pj = (fi & 3) * kRowB + (fi >> 2);                                 // LDS offset of MFMA column fi inside a strip: (row fi%4, column fi/4)
+    // LDS offset of MFMA column fi of column tile c: quad form (row fi%4, column 8c + fi/4); planar form pixel 32c + fi = segment c, offset fi
+    const int pj = QUAD_OUT ? (fi & 3) * kRowB + (fi >> 2) : fi;
+    constexpr int kTileStep = QUAD_OUT ? 8 : kRowB;
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -85,7 +95,7 @@ k_conv1x1_quad(const float *__restrict__ x, const float *__restrict__ w, const f
 #pragma unroll
             for (int i = 0; i < 2; ++i) af[i] = A[(wm + 32 * i + fi) * kLdA + k + fk];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = Bm[(k + fk) * kLdB + (wn + j) * 8 + pj];
+            for (int j = 0; j < 2; ++j) bf[j] = Bm[(k + fk) * kLdB + (wn + j) * kTileStep + pj];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -96,31 +106,56 @@ k_conv1x1_quad(const float *__restrict__ x, const float *__restrict__ w, const f
     }
 
     // epilogue: accumulator register r of lane (fi, fk) is output row 8*(r/4) + 4*fk + r%4, column fi of the MFMA tile
-    const int Q = Cout >> 2;
-    const int py = y0 + (fi & 3);
+    if constexpr (QUAD_OUT) {
+        const int Q = Cout >> 2;
+        const int py = y0 + (fi & 3);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int px = x0 + (wn + j) * 8 + (fi >> 2);
+            for (int j = 0; j < 2; ++j) {
+                const int px = x0 + (wn + j) * 8 + (fi >> 2);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = m0 + wm + 32 * i + 8 * g + 4 * fk;               // first of 4 consecutive channels
-                float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-                if (bias) { const float4 bq = *reinterpret_cast<const float4 *>(bias + co); o.x += bq.x; o.y += bq.y; o.z += bq.z; o.w += bq.w; }
-                dst[(bv * Q + (co >> 2)) * HW + (long long)px * H + py] = o;
+                for (int g = 0; g < 4; ++g) {
+                    const int co = m0 + wm + 32 * i + 8 * g + 4 * fk;               // first of 4 consecutive channels
+                    float4 o = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    if (bias) { const float4 bq = *reinterpret_cast<const float4 *>(bias + co); o.x += bq.x; o.y += bq.y; o.z += bq.z; o.w += bq.w; }
+                    dst[(bv * Q + (co >> 2)) * HW + (long long)px * H + py] = o;
+                }
             }
-        }
+    } else {
+        float *out = reinterpret_cast<float *>(dst) + bv * Cout * HW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int px = p0 + (wn + j) * 32 + fi;                           // 32 lanes = 128 contiguous bytes of one channel
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * fk + (r & 3);
+                    out[(long long)co * HW + px] = acc[i][j][r] + (bias ? bias[co] : 0.f);
+                }
+            }
+    }
 }
 
 bool conv1x1_quad_supported(int Cin, int Cout, int H, int W) { return Cin % kTK == 0 && Cout % kTM == 0 && H % 4 == 0 && W % 32 == 0; }
+bool conv1x1_planar_supported(int Cin, int Cout, int HW) { return Cin % kTK == 0 && Cout % kTM == 0 && HW % kTN == 0; }
 
 hipError_t launch_conv1x1_quad(const float *x, const float *w, const float *bias, void *dst, int BV, int Cin, int Cout, int H, int W,
                                hipStream_t s)
 {
     if (!conv1x1_quad_supported(Cin, Cout, H, W)) return hipErrorNotSupported;
     const dim3 grid((W / 32) * (H / 4), Cout / kTM, BV);
-    hipLaunchKernelGGL(k_conv1x1_quad, grid, dim3(256), 0, s, x, w, bias, (float4 *)dst, Cin, Cout, H, W);
+    hipLaunchKernelGGL(k_conv1x1_quad<true>, grid, dim3(256), 0, s, x, w, bias, (float4 *)dst, Cin, Cout, H, W);
+    return hipGetLastError();
+}
+
+// y[bv, co, p] = sum_ci w[co, ci] * x[bv, ci, p] (+ bias[co]), everything planar fp32
+hipError_t launch_conv1x1_planar(const float *x, const float *w, const float *bias, float *dst, int BV, int Cin, int Cout, int HW, hipStream_t s)
+{
+    if (!conv1x1_planar_supported(Cin, Cout, HW)) return hipErrorNotSupported;
+    const dim3 grid(HW / kTN, Cout / kTM, BV);
+    hipLaunchKernelGGL(k_conv1x1_quad<false>, grid, dim3(256), 0, s, x, w, bias, (float4 *)dst, Cin, Cout, 1, HW);
     return hipGetLastError();
 }
 

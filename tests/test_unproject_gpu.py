@@ -842,6 +842,30 @@ def test_conv1x1_to_quad_matches_conv2d_and_the_layout_pass(gpu):
     assert torch.equal(conv_copy[: ref.numel()].view_as(ref), ref)
 
 
+def test_conv1x1_planar_matches_matmul(gpu):
+    """mvhmr_conv1x1_planar (the same MFMA GEMM with a planar epilogue; the fused route's input gradient) == W @ x (+ bias)"""
+    L = _capi.lib()
+    torch.manual_seed(4)
+    BV, Cin, Cout, HW = 5, 80, 128, 3 * 128
+    x = torch.randn(BV, Cin, HW, device=gpu)
+    w = torch.randn(Cout, Cin, device=gpu) * 0.1
+    b = torch.randn(Cout, device=gpu)
+    vp = ctypes.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    assert L.mvhmr_conv1x1_planar_supported(Cin, Cout, HW) == 1
+    assert L.mvhmr_conv1x1_planar_supported(Cin, Cout, HW + 64) == 0 and L.mvhmr_conv1x1_planar_supported(Cin + 8, Cout, HW) == 0
+    ref64 = torch.matmul(w.double(), x.double())
+    for bias in (None, b):
+        y = torch.empty(BV, Cout, HW, device=gpu)
+        _capi.check(L.mvhmr_conv1x1_planar(vp(x.data_ptr()), vp(w.data_ptr()), vp(bias.data_ptr()) if bias is not None else vp(0), vp(y.data_ptr()),
+                                           BV, Cin, Cout, HW, stream))
+        ref = ref64 + (bias.double().view(1, -1, 1) if bias is not None else 0)
+        record_err("planar 1x1 conv vs float64 matmul (bias %s)" % (bias is not None), float((y.double() - ref).abs().max()),
+                   2e-6 * float(ref.abs().max()) * Cin ** 0.5 + 1e-6)
+    with pytest.raises(RuntimeError):
+        _capi.check(L.mvhmr_conv1x1_planar(vp(x.data_ptr()), vp(w.data_ptr()), vp(0), vp(y.data_ptr()), BV, Cin, Cout, HW + 64, stream))
+
+
 @pytest.mark.parametrize("training", (False, True))
 def test_volume_generator_fused_path_equals_the_unfused_one(training, gpu):
     """VolumeGenerator with the fused conv (default where the brick kernels run) against the same module with fused_conv off:
