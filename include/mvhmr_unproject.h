@@ -188,6 +188,17 @@ int mvhmr_conv1x1_planar(const float *x, const float *weight, const float *bias,
 int mvhmr_conv1x1_planar_supported(int32_t c_in, int32_t c_out, int32_t pixels);
 
 /*
+ * Weight and bias gradient of process_feature (autograd through models/aggregation.py:189-191):
+ *     grad_weight[co, ci] += sum over maps and pixels of grad_y[n, co, p] * x[n, ci, p]      grad_bias[co] += sum of grad_y[n, co, p]
+ * grad_y (n_maps, c_out, pixels), x (n_maps, c_in, pixels) fp32 planar.  grad_weight (c_out, c_in) and grad_bias (c_out, may be
+ * NULL) are ADDED INTO with float atomics (zero them first; last-bit run-to-run differences like any split-K reduction).
+ * Shapes: c_in % 128 == 0, c_out % 128 == 0, pixels % 32 == 0 (mvhmr_conv1x1_wgrad_supported), else MVHMR_ERR_UNSUPPORTED.
+ */
+int mvhmr_conv1x1_wgrad(const float *grad_y, const float *x, float *grad_weight, float *grad_bias, int32_t n_maps, int32_t c_in,
+                        int32_t c_out, int32_t pixels, void *hip_stream);
+int mvhmr_conv1x1_wgrad_supported(int32_t c_in, int32_t c_out, int32_t pixels);
+
+/*
  * Caller-side helper of VolumeGenerator.forward (models/aggregation.py:138-187): fills
  * coords (B,S,S,S,3) fp32 with the cuboid grid `position + side/(S-1) * (i,j,k)` rotated by
  * rot[b] (3x3 row-major fp32, utils/volumetric.py:87-114) about center[b] (3 fp32):

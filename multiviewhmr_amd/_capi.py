@@ -22,7 +22,7 @@ EXPORTS = (
     "mvhmr_unproject_selected_variant", "mvhmr_preferred_layout", "mvhmr_feature_layout_bytes", "mvhmr_convert_features",
     "mvhmr_unproject_query_variant", "mvhmr_internal_lds_cache_key",
     "mvhmr_unproject_forward_cuboid", "mvhmr_unproject_backward_cuboid",
-    "mvhmr_conv1x1_to_quad", "mvhmr_conv1x1_to_quad_supported", "mvhmr_conv1x1_planar", "mvhmr_conv1x1_planar_supported", "mvhmr_unproject_query_variant_cuboid",
+    "mvhmr_conv1x1_to_quad", "mvhmr_conv1x1_to_quad_supported", "mvhmr_conv1x1_planar", "mvhmr_conv1x1_planar_supported", "mvhmr_conv1x1_wgrad", "mvhmr_conv1x1_wgrad_supported", "mvhmr_unproject_query_variant_cuboid",
 )
 
 
@@ -76,6 +76,10 @@ def lib():
     L.mvhmr_conv1x1_planar.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.mvhmr_conv1x1_planar_supported.restype = ctypes.c_int
     L.mvhmr_conv1x1_planar_supported.argtypes = [i32, i32, i32]
+    L.mvhmr_conv1x1_wgrad.restype = ctypes.c_int
+    L.mvhmr_conv1x1_wgrad.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
+    L.mvhmr_conv1x1_wgrad_supported.restype = ctypes.c_int
+    L.mvhmr_conv1x1_wgrad_supported.argtypes = [i32, i32, i32]
     L.mvhmr_unproject_query_variant_cuboid.restype = ctypes.c_int
     L.mvhmr_unproject_query_variant_cuboid.argtypes = [dp, vp, vp, vp, d3, d3, vp]
     L.mvhmr_preferred_layout.restype = ctypes.c_int

@@ -308,10 +308,18 @@ class _FusedAggregate(torch.autograd.Function):
                     _capi.check(L.mvhmr_conv1x1_planar(_ptr(gy), _ptr(wt), ctypes.c_void_p(0), _ptr(gx), B * V, Cout, Cin, Hf * Wf, _stream(dev)))
             else:
                 gx = torch.matmul(w2.t(), gy).view(B, V, Cin, Hf, Wf)
-        if ctx.needs_input_grad[1]:
-            gw = torch.einsum("nop,nip->oi", gy, xf).view(ctx.wshape)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = gy.sum(dim=(0, 2))
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and L.mvhmr_conv1x1_wgrad_supported(Cin, Cout, Hf * Wf):
+            gw = torch.zeros(ctx.wshape, dtype=torch.float32, device=dev)                      # split-K GEMM adds into it
+            gb = torch.zeros(Cout, dtype=torch.float32, device=dev) if want_b else None
+            with torch.cuda.device(dev):
+                _capi.check(L.mvhmr_conv1x1_wgrad(_ptr(gy), _ptr(x), _ptr(gw), _ptr(gb) if want_b else ctypes.c_void_p(0), B * V, Cin, Cout,
+                                                  Hf * Wf, _stream(dev)))
+        else:
+            if ctx.needs_input_grad[1]:
+                gw = torch.einsum("nop,nip->oi", gy, xf).view(ctx.wshape)
+            if want_b:
+                gb = gy.sum(dim=(0, 2))
         return gx, gw, gb, None, None, None, None, None, None, None
 
 

@@ -479,6 +479,22 @@ int mvhmr_conv1x1_planar_supported(int32_t c_in, int32_t c_out, int32_t pixels)
     return conv1x1_planar_supported(c_in, c_out, pixels) ? 1 : 0;
 }
 
+int mvhmr_conv1x1_wgrad(const float *grad_y, const float *x, float *grad_weight, float *grad_bias, int32_t n_maps, int32_t c_in,
+                        int32_t c_out, int32_t pixels, void *hip_stream)
+{
+    if (!grad_y || !x || !grad_weight) return fail(MVHMR_ERR_INVALID_ARGUMENT, "null pointer");
+    if (n_maps <= 0 || c_in <= 0 || c_out <= 0 || pixels <= 0) return fail(MVHMR_ERR_INVALID_ARGUMENT, "non-positive extent");
+    if (!conv1x1_wgrad_supported(c_in, c_out, pixels))
+        return fail(MVHMR_ERR_UNSUPPORTED, "1x1 conv weight gradient needs C_in %% 128 == 0, C_out %% 128 == 0, pixels %% 32 == 0 (got %d -> %d, %d)", c_in, c_out, pixels);
+    return launched(launch_conv1x1_wgrad(grad_y, x, grad_weight, grad_bias, n_maps, c_in, c_out, pixels, static_cast<hipStream_t>(hip_stream)),
+                    "1x1 conv weight gradient");
+}
+
+int mvhmr_conv1x1_wgrad_supported(int32_t c_in, int32_t c_out, int32_t pixels)
+{
+    return conv1x1_wgrad_supported(c_in, c_out, pixels) ? 1 : 0;
+}
+
 int mvhmr_unproject_query_variant_cuboid(const mvhmr_unproject_desc *desc, const float *proj, const float *rot, const float *center,
                                          const double position[3], const double sides[3], void *hip_stream)
 {

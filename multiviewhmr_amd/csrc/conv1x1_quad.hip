@@ -159,6 +159,105 @@ hipError_t launch_conv1x1_planar(const float *x, const float *w, const float *bi
     return hipGetLastError();
 }
 
+// Weight and bias gradient of the 1x1 conv:  dW[co, ci] += sum_{bv, p} gy[bv, co, p] * x[bv, ci, p],  db[co] += sum gy[bv, co, p]
+// (autograd through models/aggregation.py:189-191).  A GEMM with M = Cout, N = Cin and K = BV * H * W (1.2 M at the north-star size):
+// split along K over the grid -- a block owns a 128 x 128 tile of dW and one slice of one map's pixels, stages 32-pixel chunks of both
+// operands through LDS ([row][k], stride 33: conflict-free fragment reads), keeps the next chunk in registers while the MFMAs run, and
+// adds its partial tile with float atomics shaped as 128 contiguous bytes per wave row (dW / db are zeroed by the caller).
+namespace {
+constexpr int kWK = 32;                         // pixels per chunk
+constexpr int kWLd = kWK + 1;
+}  // namespace
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_conv1x1_wgrad(const float *__restrict__ gy, const float *__restrict__ x, float *__restrict__ dW, float *__restrict__ db,
+                int Cout, int Cin, int HW, int slices_per_map, int slice_px)
+{
+    __shared__ float sA[kTM * kWLd];
+    __shared__ float sB[kTN * kWLd];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bv = blockIdx.x / slices_per_map, p_begin = (blockIdx.x % slices_per_map) * slice_px;
+    const int m0 = blockIdx.y * kTM, n0 = blockIdx.z * kTN;
+    // global -> LDS: thread t stages 16 consecutive pixels of row t / 2 of both tiles
+    const int row = tid >> 1, kp = (tid & 1) << 4;
+    const float *ga = gy + ((long long)bv * Cout + m0 + row) * HW + p_begin + kp;
+    const float *gb = x + ((long long)bv * Cin + n0 + row) * HW + p_begin + kp;
+    float4 a0, a1, a2, a3, b0, b1, b2, b3;
+    float bsum = 0.f;
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+        const float4 *pa = reinterpret_cast<const float4 *>(ga + k0), *pb = reinterpret_cast<const float4 *>(gb + k0);
+        a0 = pa[0]; a1 = pa[1]; a2 = pa[2]; a3 = pa[3];
+        b0 = pb[0]; b1 = pb[1]; b2 = pb[2]; b3 = pb[3];
+    };
+    auto put4 = [&](float *d, const float4 &v) __attribute__((always_inline)) { d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w; };
+    auto lstore = [&]() __attribute__((always_inline)) {
+        float *a = &sA[row * kWLd + kp], *b = &sB[row * kWLd + kp];
+        put4(a, a0); put4(a + 4, a1); put4(a + 8, a2); put4(a + 12, a3);
+        put4(b, b0); put4(b + 4, b1); put4(b + 8, b2); put4(b + 12, b3);
+        bsum += ((a0.x + a0.y) + (a0.z + a0.w)) + ((a1.x + a1.y) + (a1.z + a1.w)) + ((a2.x + a2.y) + (a2.z + a2.w)) + ((a3.x + a3.y) + (a3.z + a3.w));
+    };
+    const int wm = (wave >> 1) << 6, wn = (wave & 1) << 6;
+    const int fi = lane & 31, fk = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = slice_px / kWK;
+    gload(0);
+    for (int kc = 0; kc < nk; ++kc) {
+        __syncthreads();                                                         // every wave has read the previous chunk
+        lstore();
+        __syncthreads();
+        if (kc + 1 < nk) gload((kc + 1) * kWK);                                   // in flight under the MFMAs
+#pragma unroll
+        for (int k = 0; k < kWK; k += 2) {
+            float af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = sA[(wm + 32 * i + fi) * kWLd + k + fk];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = sB[(wn + 32 * j + fi) * kWLd + k + fk];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // accumulator register r of lane (fi, fk): row 8*(r/4) + 4*fk + r%4 (co), column fi (ci)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = m0 + wm + 32 * i + 8 * (r >> 2) + 4 * fk + (r & 3);
+                atomicAdd(dW + (long long)co * Cin + n0 + wn + 32 * j + fi, acc[i][j][r]);
+            }
+    if (db && blockIdx.z == 0) {
+        bsum += __shfl_xor(bsum, 1);
+        if ((tid & 1) == 0) atomicAdd(db + m0 + row, bsum);
+    }
+}
+
+bool conv1x1_wgrad_supported(int Cin, int Cout, int HW) { return Cin % kTN == 0 && Cout % kTM == 0 && HW % kWK == 0; }
+
+// dW (Cout, Cin) and db (Cout, may be null) are ADDED INTO: zero them first
+hipError_t launch_conv1x1_wgrad(const float *gy, const float *x, float *dW, float *db, int BV, int Cin, int Cout, int HW, hipStream_t s)
+{
+    if (!conv1x1_wgrad_supported(Cin, Cout, HW)) return hipErrorNotSupported;
+    // slices per map: enough blocks to fill the chip a few times, slices of whole chunks
+    const int chunks = HW / kWK, tiles = (Cout / kTM) * (Cin / kTN);
+    int spm = 1;
+    for (int c = 1; c <= chunks; ++c)
+        if (chunks % c == 0 && (long long)BV * c * tiles <= 2048) spm = c;
+    const dim3 grid(BV * spm, Cout / kTM, Cin / kTN);
+    hipLaunchKernelGGL(k_conv1x1_wgrad, grid, dim3(256), 0, s, gy, x, dW, db, Cout, Cin, HW, spm, (chunks / spm) * kWK);
+    return hipGetLastError();
+}
+
 // column-major quad-planar (BV, C/4, W, H, 4) -> row-major quad-planar (BV, C/4, H, W, 4): what the brick backward stages, when the
 // forward kept only the fused copy.  32 x 32 pixel tiles through LDS, 512-B runs both ways.
 __global__ void __launch_bounds__(256)

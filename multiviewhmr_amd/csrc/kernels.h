@@ -77,6 +77,8 @@ hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Probl
 // process_feature fused with the layout pass: y = W x + b as an fp32 MFMA GEMM writing the column-major quad-planar copy
 bool conv1x1_quad_supported(int Cin, int Cout, int H, int W);
 bool conv1x1_planar_supported(int Cin, int Cout, int HW);
+bool conv1x1_wgrad_supported(int Cin, int Cout, int HW);
+hipError_t launch_conv1x1_wgrad(const float *gy, const float *x, float *dW, float *db, int BV, int Cin, int Cout, int HW, hipStream_t s);
 hipError_t launch_conv1x1_planar(const float *x, const float *w, const float *bias, float *dst, int BV, int Cin, int Cout, int HW, hipStream_t s);
 hipError_t launch_conv1x1_quad(const float *x, const float *w, const float *bias, void *dst, int BV, int Cin, int Cout, int H, int W,
                                hipStream_t s);

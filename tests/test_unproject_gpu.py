@@ -866,6 +866,30 @@ def test_conv1x1_planar_matches_matmul(gpu):
         _capi.check(L.mvhmr_conv1x1_planar(vp(x.data_ptr()), vp(w.data_ptr()), vp(0), vp(y.data_ptr()), BV, Cin, Cout, HW + 64, stream))
 
 
+def test_conv1x1_wgrad_matches_einsum(gpu):
+    """mvhmr_conv1x1_wgrad (split-K MFMA GEMM + float atomics) == sum_n gy[n] @ x[n]^T and the row sums of gy, added into the outputs"""
+    L = _capi.lib()
+    torch.manual_seed(5)
+    BV, Cin, Cout, HW = 7, 128, 256, 20 * 32
+    x = torch.randn(BV, Cin, HW, device=gpu)
+    gy = torch.randn(BV, Cout, HW, device=gpu)
+    vp = ctypes.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    assert L.mvhmr_conv1x1_wgrad_supported(Cin, Cout, HW) == 1
+    assert L.mvhmr_conv1x1_wgrad_supported(Cin + 64, Cout, HW) == 0 and L.mvhmr_conv1x1_wgrad_supported(Cin, Cout, HW + 16) == 0
+    ref_w = torch.einsum("nop,nip->oi", gy.double(), x.double())
+    ref_b = gy.double().sum(dim=(0, 2))
+    gw = torch.full((Cout, Cin), 1.0, device=gpu)                                 # "added into": starts from ones
+    gb = torch.zeros(Cout, device=gpu)
+    _capi.check(L.mvhmr_conv1x1_wgrad(vp(gy.data_ptr()), vp(x.data_ptr()), vp(gw.data_ptr()), vp(gb.data_ptr()), BV, Cin, Cout, HW, stream))
+    K = BV * HW
+    record_err("1x1 conv weight gradient vs float64 einsum", float((gw.double() - 1.0 - ref_w).abs().max()), 4e-7 * K ** 0.5 * 8 + 1e-5)
+    record_err("1x1 conv bias gradient vs float64 sum", float((gb.double() - ref_b).abs().max()), 4e-7 * K ** 0.5 * 8 + 1e-5)
+    gw2 = torch.zeros(Cout, Cin, device=gpu)
+    _capi.check(L.mvhmr_conv1x1_wgrad(vp(gy.data_ptr()), vp(x.data_ptr()), vp(gw2.data_ptr()), vp(0), BV, Cin, Cout, HW, stream))   # no bias
+    record_err("1x1 conv weight gradient (no bias) vs float64 einsum", float((gw2.double() - ref_w).abs().max()), 4e-7 * K ** 0.5 * 8 + 1e-5)
+
+
 @pytest.mark.parametrize("training", (False, True))
 def test_volume_generator_fused_path_equals_the_unfused_one(training, gpu):
     """VolumeGenerator with the fused conv (default where the brick kernels run) against the same module with fused_conv off:
