@@ -450,10 +450,8 @@ hipError_t launch_bm(const float4 *featK, const TO *grad_out, const float *proj,
         if (bwd_brick_z(p) == 16) return launch_bv<METHOD, 4, kNTb, TO, 16>(featK, grad_out, proj, coords, gradK, p, s);
         return launch_bv<METHOD, 4, kNTb, TO>(featK, grad_out, proj, coords, gradK, p, s);
     case 8:
-        if constexpr (sizeof(TO) == 4) {
-            if (bwd_brick_z(p) == 16) return launch_bv<METHOD, 8, kNTb8, TO, 16>(featK, grad_out, proj, coords, gradK, p, s);
-            return launch_bv<METHOD, 8, kNTb8, TO>(featK, grad_out, proj, coords, gradK, p, s);
-        }
+        if (bwd_brick_z(p) == 16) return launch_bv<METHOD, 8, kNTb8, TO, 16>(featK, grad_out, proj, coords, gradK, p, s);
+        return launch_bv<METHOD, 8, kNTb8, TO>(featK, grad_out, proj, coords, gradK, p, s);
         break;
     }
     return hipErrorNotSupported;
@@ -496,7 +494,6 @@ bool brick_bwd_supported(const Problem &p)
 {
     if (p.feat_f16 != p.out_f16) return false;                            // fp32 or fp16 storage throughout; mixed -> gather
     if (p.V != 2 && p.V != 4 && p.V != 8) return false;
-    if (p.V == 8 && p.out_f16) return false;
     const int nt = p.V == 8 ? kNTb8 : kNTb;
     if (p.C % 4) return false;
     if (bwd_brick_z(p) != 16 && (p.Z % kBZ || p.X % kBX || p.Y % (nt / 128))) return false;

@@ -330,10 +330,11 @@ def test_channels_last_features_skip_the_layout_pass(gpu):
     assert float((cl.grad - pl.grad).abs().max()) <= 1e-5
 
 
-def test_fp16_storage_mode(gpu):
+@pytest.mark.parametrize("views", (4, 8))
+def test_fp16_storage_mode(views, gpu):
     """fp16 features / volume, fp32 geometry and accumulation; oracle evaluated on the fp16-rounded inputs.
     Bound: half an fp16 ulp of the output magnitude (~2^-11 * |x|) plus the fp32 bar."""
-    feats, proj, coords = _ring_problem(B=1, V=4, C=32, H=32, W=32, vol=(8, 8, 32), seed=11)
+    feats, proj, coords = _ring_problem(B=1, V=views, C=32, H=32, W=32, vol=(8, 8, 32), seed=11)
     f16 = torch.from_numpy(feats).to(gpu).half()
     p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
     ref = cport.forward(f16.float().cpu().numpy(), proj, coords, "softmax")
