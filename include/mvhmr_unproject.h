@@ -73,8 +73,9 @@ typedef enum mvhmr_variant_t {
     MVHMR_VARIANT_GATHER = 1, /* channel-per-lane gather from L2, any shape */
     MVHMR_VARIANT_BRICK = 2   /* voxel bricks with LDS-staged feature windows (forward) and LDS-accumulated
                                  gradient windows (backward): C % 4 == 0, 2 / 4 / 8 views, volume divisible into 4 x 8 x 32
-                                 bricks (4 x 4 x 32 with 8 views; the forward doubles the bricks in x when vol_x % 8 == 0);
-                                 the backward needs one storage type throughout and has no 8-view fp16 kernel;
+                                 bricks (4 x 4 x 32 with 8 views; the forward doubles the bricks in x when vol_x % 8 == 0; the
+                                 backward uses 8 x 8 x 16 -- 8 x 4 x 16 with 8 views -- when the volume divides that way);
+                                 the backward needs one storage type throughout;
                                  anything else is MVHMR_ERR_UNSUPPORTED */
 } mvhmr_variant_t;
 
