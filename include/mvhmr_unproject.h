@@ -73,7 +73,8 @@ typedef enum mvhmr_variant_t {
     MVHMR_VARIANT_GATHER = 1, /* channel-per-lane gather from L2, any shape */
     MVHMR_VARIANT_BRICK = 2   /* voxel bricks with LDS-staged feature windows (forward) and LDS-accumulated
                                  gradient windows (backward): C % 4 == 0, 2 / 4 / 8 views, volume divisible into 4 x 8 x 32
-                                 bricks (4 x 4 x 32 with 8 views; the forward doubles the bricks in x when vol_x % 8 == 0; the
+                                 bricks (8 views: 4 x 4 x 32, in the forward 4 x 8 x 32 with the views staged in two groups
+                                 when vol_y % 8 == 0; the forward doubles the bricks in x when vol_x % 8 == 0 for 2 / 4 views; the
                                  backward uses 8 x 8 x 16 -- 8 x 4 x 16 with 8 views -- when the volume divides that way);
                                  the backward needs one storage type throughout;
                                  anything else is MVHMR_ERR_UNSUPPORTED */

@@ -1,0 +1,271 @@
+// Brick forward for 8 views at full occupancy: 1024 threads, one voxel per lane, 4 x 8 x 32 bricks, the views staged in GROUPS.
+//
+// k_fwd_brick serves 8 views with 512-thread blocks (a lane's 8 tap records, 2 x 32 sample registers and two tap sets need ~170
+// VGPRs: two waves per SIMD) and 4 x 4 x 32 bricks (eight windows of a bigger brick overflow the LDS ring).  Here a ring item is
+// (channel quad, view group): only the windows of VG = 4 views are resident at a time, so a 4 x 8 x 32 brick fits a 2-deep ring
+// (group windows: mean 2 500, max 4 000 slots at the configs[3] geometry; 29 % fewer window pixels per voxel than 4 x 4 x 32), and a
+// lane keeps one tap set and the 32 samples of its voxel: 128 VGPRs, four waves per SIMD.  The samples of both groups meet in
+// registers and go through the same aggregate<METHOD, 8> as in k_fwd_brick: identical results.
+// Same lane map, column-major windows, stride-4 DPP transpose and stores as k_fwd_brick (brick_fwd_kernel.h).
+#pragma once
+#include "brick_fwd_kernel.h"
+
+namespace mvhmr {
+
+constexpr int kGroupViews = 4;
+constexpr int kGroupChunks = 4;                       // DMA chunks a wave may own per ring item: 16 waves x 4 x 64 = 4 096 slots
+
+// one voxel sampled straight from global memory: taps rebuilt from the projection (clamped taps, zero weights outside)
+template <int METHOD, int VT, typename TO>
+__device__ __attribute__((noinline)) void fwd_groups_slow(const float4 *fk, TO *obase, const float (*proj)[12], const Coords &coords, int b,
+                                                          long long N, unsigned vox, int nq, int H, int W)
+{
+    const int HW = H * W;
+    float c0, c1, c2;
+    voxel_xyz(coords, b, N, vox, c0, c1, c2);
+    float w00[VT], w01[VT], w10[VT], w11[VT];
+    int o00[VT], o01[VT], o10[VT], o11[VT];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        const Taps t = make_taps(proj[v], c0, c1, c2, H, W);
+        w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
+        const int base = (v * nq) * HW;
+        o00[v] = base + t.x0 * H + t.y0; o01[v] = base + t.x1 * H + t.y0; o10[v] = base + t.x0 * H + t.y1; o11[v] = base + t.x1 * H + t.y1;
+    }
+    for (int q = 0; q < nq; ++q) {
+        const float4 *src = fk + (long long)q * HW;
+        float s[4][VT];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const float4 a = src[o00[v]], bb = src[o01[v]], c = src[o10[v]], d = src[o11[v]];
+            s[0][v] = bilerp(a.x, bb.x, c.x, d.x, w00[v], w01[v], w10[v], w11[v]);
+            s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[v], w01[v], w10[v], w11[v]);
+            s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]);
+            s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]);
+        }
+        TO *oq = obase + (long long)(q * 4) * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) (oq + i * N)[vox] = from_f32<TO>(aggregate<METHOD, VT>(s[i]));
+    }
+}
+
+template <int METHOD, int VT, typename TO>
+__global__ void __launch_bounds__(1024)
+k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords, TO *__restrict__ out, int C,
+                   int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample, int lds_slots, int total_blocks, Gate gate)
+{
+    if (gated_off(gate)) return;
+    constexpr int NT = 1024, BY = NT / 128, NW = NT / 64, VG = kGroupViews, NG = VT / VG, MC = kGroupChunks;
+    static_assert(VT == 2 * VG, "two view groups");
+    extern __shared__ __align__(16) unsigned char smem[];
+    FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + lds_slots * 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
+
+    // XCD-aware order as in k_fwd_brick
+    const int nbx = bricks_per_sample / (nby * nbz);
+    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
+    const int tw = (nbx + tiles_x - 1) / tiles_x, th = (nby + tiles_y - 1) / tiles_y;
+    const int share = tw * th * nbz;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int b = j / share, r = j % share;
+    const int kz = r % nbz, cy = (r / nbz) % th, cx = r / (nbz * th);
+    const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
+    if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
+    const long long N = (long long)X * Y * Z;
+    const int HW = H * W, nq = C >> 2;
+
+    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = proj[((long long)b * VT) * 12 + tid];
+    if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
+    __syncthreads();
+
+    // ---- this lane's voxel and its tap records (once per brick)
+    int dcol, zin;
+    fwd_lane_voxel(lane, dcol, zin);
+    const int col = wave * 2 + dcol;
+    const int vx = kx * kBX + (col & 3), vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
+    const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_supported)
+    float w00[VT], w01[VT], w10[VT], w11[VT];
+    int tx[VT], ty[VT];
+    unsigned valid = 0;
+    {
+        float c0, c1, c2;
+        voxel_xyz(coords, b, N, vox, c0, c1, c2);
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
+            w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
+            tx[v] = t.rx0; ty[v] = t.ry0;
+            if (t.any) valid |= 1u << v;
+            const int big = 1 << 30;
+            const int nxmin = wave_max_dpp(t.any ? -t.rx0 : -big), nymin = wave_max_dpp(t.any ? -t.ry0 : -big);
+            const int xmax = wave_max_dpp(t.any ? t.rx0 : -big), ymax = wave_max_dpp(t.any ? t.ry0 : -big);
+            if (lane == 0 && xmax >= -nxmin) {
+                atomicMin(&sh->bbox[v][0], -nxmin); atomicMin(&sh->bbox[v][1], -nymin);
+                atomicMax(&sh->bbox[v][2], xmax); atomicMax(&sh->bbox[v][3], ymax);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- window per view (block-uniform); the views of a group are packed back to back, every group starts at slot 0
+    int wx0[VT], wy0[VT], ws[VT], slot0[VT], nch[NG][VG + 1];
+    int used = 0, max_stride = 0, max_chunks = 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        int ug = 0;
+        nch[g][0] = 0;
+#pragma unroll
+        for (int u = 0; u < VG; ++u) {
+            const int v = g * VG + u;
+            const int xmin = uniform(sh->bbox[v][0]), ymin = uniform(sh->bbox[v][1]);
+            const int xmax = uniform(sh->bbox[v][2]), ymax = uniform(sh->bbox[v][3]);
+            int bw = 0, bh = 0;
+            if (xmax >= xmin) { bw = xmax - xmin + 2; bh = ymax - ymin + 2; }
+            const int stride = bh | 1;
+            const int chunks = (stride * bw + 63) >> 6;
+            wx0[v] = xmin; wy0[v] = ymin; ws[v] = stride;
+            max_stride = stride > max_stride ? stride : max_stride;
+            slot0[v] = ug;
+            ug += chunks << 6;
+            nch[g][u + 1] = nch[g][u] + chunks;
+        }
+        used = ug > used ? ug : used;
+        max_chunks = nch[g][VG] > max_chunks ? nch[g][VG] : max_chunks;
+    }
+    const int cap = fwd_cap2(lds_slots);
+    const int buf_bytes = kZeroBytes + cap * 16;
+    const bool fits = used <= cap && max_chunks <= MC * NW && max_stride + 2 <= kZeroSlots;
+    TO *const obase = out + (long long)b * C * N;
+    const float4 *const fk = featK + (long long)b * VT * nq * HW;
+
+    if (fits) {
+        for (int i = tid; i < kZeroSlots * 2; i += NT)
+            *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        int a0[VT], ws16[VT];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            ws16[v] = ws[v] * 16;
+            const bool ok = (valid >> v) & 1u;
+            const int s0 = slot0[v] + (tx[v] - wx0[v]) * ws[v] + (ty[v] - wy0[v]);
+            a0[v] = ok ? kZeroBytes + s0 * 16 : 0;
+        }
+        // ---- DMA chunks of this wave, per group: chunk c covers 64 consecutive slots of one view's window
+        unsigned g_off[NG][MC];
+        int l_dst[NG][MC];
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int rr = 0; rr < MC; ++rr) {
+                const int c = wave + rr * NW;
+                l_dst[g][rr] = -1;
+                g_off[g][rr] = 0;
+                if (c < nch[g][VG]) {
+                    int u = 0;
+#pragma unroll
+                    for (int uu = 1; uu < VG; ++uu) u += c >= nch[g][uu] ? 1 : 0;
+                    int sv = ws[g * VG], ox = wx0[g * VG], oy = wy0[g * VG], c0 = nch[g][0], s0 = slot0[g * VG];
+#pragma unroll
+                    for (int uu = 1; uu < VG; ++uu)
+                        if (u == uu) { sv = ws[g * VG + uu]; ox = wx0[g * VG + uu]; oy = wy0[g * VG + uu]; c0 = nch[g][uu]; s0 = slot0[g * VG + uu]; }
+                    const int jj = c - c0, slot = (jj << 6) + lane;
+                    const int px = slot / sv, py = slot - px * sv;
+                    int gx = ox + px, gy = oy + py;
+                    gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
+                    gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+                    g_off[g][rr] = (unsigned)(((g * VG + u) * nq) * HW + gx * H + gy) * 16u;
+                    l_dst[g][rr] = kZeroBytes + (s0 + (jj << 6)) * 16;
+                }
+            }
+        const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
+        // ring item t = NG * quad + group, buffer t & 1
+        auto dma = [&](int q, auto gtag) __attribute__((always_inline)) {
+            constexpr int g = decltype(gtag)::value;
+            const float4 *src = fk + (long long)q * HW;
+            const int boff = ((q * NG + g) & 1) * buf_bytes;
+#pragma unroll
+            for (int rr = 0; rr < MC; ++rr)
+                if (l_dst[g][rr] >= 0) glds16(src, g_off[g][rr], lds_base + (unsigned)uniform(l_dst[g][rr] + boff));
+        };
+
+        constexpr unsigned OSZ = sizeof(TO);
+        const unsigned chan_bytes = (unsigned)(N * OSZ);
+        const int z0 = ((lane >> 5) << 4) + ((lane & 3) << 2);
+        const unsigned st_off = (vox - (unsigned)zin + (unsigned)z0) * OSZ + (unsigned)((lane >> 2) & 3) * chan_bytes;
+        auto store_quad = [&](int q, float (&res)[4]) __attribute__((always_inline)) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
+            stride4_transpose(res, lane);
+            if constexpr (OSZ == 4) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
+                                 __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
+                __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, 18);
+            } else {
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                const __half2 lo = __floats2half2_rn(res[0], res[1]), hi = __floats2half2_rn(res[2], res[3]);
+                const u32x2 d = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+                __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)st_off, 0, 18);
+            }
+        };
+
+        float s[4][VT];
+        dma(0, std::integral_constant<int, 0>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the zero regions are written
+        // item (q, g): wait for its DMA (issued one item earlier; at most the store of the previous quad is younger), barrier
+        // (publishes the item; every wave has folded the item before, whose buffer is therefore free), request the next item,
+        // fold the group's views; after the last group aggregate, transpose, store
+#pragma nounroll
+        for (int q = 0; q < nq; ++q) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g == 0 && q > 0) wait_vmcnt(1); else wait_vmcnt(0);          // g == 0: the store of quad q-1 was issued after this DMA
+                bare_barrier();
+                if (g + 1 < NG) {
+                    if constexpr (NG > 1) dma(q, std::integral_constant<int, (NG > 1 ? 1 : 0)>{});
+                } else if (q + 1 < nq) {
+                    dma(q + 1, std::integral_constant<int, 0>{});
+                }
+                const int boff = ((q * NG + g) & 1) * buf_bytes;
+#pragma unroll
+                for (int u = 0; u < VG; ++u) {
+                    const int v = g * VG + u;
+                    int base = a0[v] + boff;
+                    asm volatile("" : "+v"(base));                               // rebuilt per use: hoisted, the 16 addresses would spill
+                    const int far = base + ws16[v];
+                    const f32x4 nw = lds_tap(smem, base), sw = lds_tap(smem, base + 16), ne = lds_tap(smem, far), se = lds_tap(smem, far + 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        s[i][v] = bilerp(nw.v[i], ne.v[i], sw.v[i], se.v[i], w00[v], w01[v], w10[v], w11[v]);
+                        asm volatile("" : "+v"(s[i][v]));
+                    }
+                }
+            }
+            float res[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res[i] = aggregate<METHOD, VT>(s[i]);
+            store_quad(q, res);
+        }
+    } else {
+        // ---- windows do not fit the LDS pool: sample straight from global memory (its own function: its registers -- 8 views of
+        // samples, weights and 64-bit addresses -- stay out of the fast path's allocation)
+        fwd_groups_slow<METHOD, VT, TO>(fk, obase, sh->proj, coords, b, N, vox, nq, H, W);
+    }
+}
+
+template <int METHOD, int VT, typename TO>
+hipError_t launch_fwd_groups_instance(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s)
+{
+    constexpr int NT = 1024;
+    const int nbx = p.X / kBX, nby = p.Y / (NT / 128), nbz = p.Z / kBZ;
+    const int bps = nbx * nby * nbz, total = bps * p.B;
+    const int slots = fwd_lds_slots();
+    const size_t lds = (size_t)slots * 16 + sizeof(FwdShared<VT>);
+    auto kern = k_fwd_brick_groups<METHOD, VT, TO>;
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
+    const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, make_gate(p, true));
+    return hipGetLastError();
+}
+
+}  // namespace mvhmr

@@ -376,6 +376,11 @@ hipError_t launch_fwd_instance(const float4 *featK, const float *proj, const Coo
     return hipGetLastError();
 }
 
+// 8 views in two groups of four, 1024 threads (brick_fwd_groups.h)
+bool brick_fwd_grouped(const Problem &p);
+template <int METHOD, int VT, typename TO>
+hipError_t launch_fwd_groups_instance(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s);
+
 // one aggregation method: views x storage type x voxels per lane
 template <int METHOD>
 hipError_t launch_fwd_method(const void *featK_, const float *proj, const Coords &coords, void *out, const Problem &p, int nvox, hipStream_t s)
@@ -385,6 +390,9 @@ hipError_t launch_fwd_method(const void *featK_, const float *proj, const Coords
     if (p.V == NVIEWS && nvox == NV)                                                                                                      \
         return p.out_f16 ? launch_fwd_instance<METHOD, NVIEWS, NTHR, __half, NV>(featK, proj, coords, (__half *)out, p, s)               \
                          : launch_fwd_instance<METHOD, NVIEWS, NTHR, float, NV>(featK, proj, coords, (float *)out, p, s)
+    if (brick_fwd_grouped(p))
+        return p.out_f16 ? launch_fwd_groups_instance<METHOD, 8, __half>(featK, proj, coords, (__half *)out, p, s)
+                         : launch_fwd_groups_instance<METHOD, 8, float>(featK, proj, coords, (float *)out, p, s);
     MVHMR_FWD_CASE(2, 1024, 1); MVHMR_FWD_CASE(2, 1024, 2);
     MVHMR_FWD_CASE(4, 1024, 1); MVHMR_FWD_CASE(4, 1024, 2);
     MVHMR_FWD_CASE(8, 512, 1);  MVHMR_FWD_CASE(8, 512, 2);

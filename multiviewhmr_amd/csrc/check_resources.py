@@ -6,7 +6,7 @@ import re
 import sys
 
 NO_SCRATCH = ("k_fwd_brick",)          # kernels with hand-counted vmcnt waits (k_bwd_brick only uses vmcnt(0))
-EXEMPT = re.compile(r"^$")
+EXEMPT = re.compile(r"k_fwd_brick_groups")   # its scratch is the frame of the cold noinline slow path; the quad loop is checked on the asm (check_loops.py)
 text = open(sys.argv[1]).read()
 bad = []
 for m in re.finditer(r"Function Name: (\S+).*?ScratchSize \[bytes/lane\]: (\d+)", text, flags=re.S):

@@ -60,6 +60,7 @@ hipError_t launch_fwd_brick(const void *featK, const float *proj, const Coords &
 // the gate decides for.
 struct GateGeom {
     int bx, by, bz;      // brick extent in voxels
+    int view_group;      // views whose windows are resident together (0: all of them)
     int column_major;    // window lines run along y (forward) or x (backward)
     int cap_slots;       // 16-B LDS slots one window set may use
     int max_chunks;      // 64-slot DMA chunks a block can issue per quad

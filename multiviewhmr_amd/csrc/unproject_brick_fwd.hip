@@ -127,6 +127,8 @@ static int fwd_threads(int V) { return V == 8 ? 512 : 1024; }          // 8 view
 // 8 x 8 x 32 bricks (two voxels per lane) when x allows; 8 views keep 4 x 4 x 32: their eight windows of a doubled brick (mean
 // ~4 300 slots, max ~6 000 at the configs[3] geometry) overflow the 2-deep ring (4 928) for most bricks
 int brick_fwd_nvox(const Problem &p) { return (p.V <= 4 && p.X % (2 * kBX) == 0) ? 2 : 1; }
+// 8 views: 1024-thread blocks on 4 x 8 x 32 bricks with the views staged in two groups of four (brick_fwd_groups.h) when y divides
+bool brick_fwd_grouped(const Problem &p) { return p.V == 8 && p.Y % 8 == 0; }
 
 bool brick_fwd_supported(const Problem &p)
 {
@@ -139,11 +141,12 @@ bool brick_fwd_supported(const Problem &p)
 
 GateGeom brick_fwd_gate_geom(const Problem &p)
 {
-    const int nt = fwd_threads(p.V);
+    const int nt = brick_fwd_grouped(p) ? 1024 : fwd_threads(p.V);
     GateGeom g;
     g.bx = kBX * brick_fwd_nvox(p); g.by = nt / 128; g.bz = kBZ; g.column_major = 1;
+    g.view_group = brick_fwd_grouped(p) ? 4 : 0;
     g.cap_slots = fwd_cap2(fwd_lds_slots());                              // the 2-deep ring still stages through LDS
-    g.max_chunks = brick_chunks_per_wave(nt) * (nt / 64);
+    g.max_chunks = brick_fwd_grouped(p) ? 4 * (nt / 64) : brick_chunks_per_wave(nt) * (nt / 64);
     return g;
 }
 
@@ -162,8 +165,9 @@ k_brick_gate(const float *__restrict__ proj, const Coords coords, int *__restric
     const int b = i / bps, r = i % bps;
     const int kz = r % nbz, ky = (r / nbz) % nby, kx = r / (nbz * nby);
     const long long N = (long long)X * Y * Z;
-    int used = 0, chunks_all = 0, max_stride = 0;
+    int used = 0, chunks_all = 0, max_stride = 0, used_max = 0, chunks_max = 0;
     for (int v = 0; v < V; ++v) {
+        if (g.view_group && v % g.view_group == 0) { used = 0; chunks_all = 0; }    // a new group of views starts from an empty buffer
         const float *P = proj + ((long long)b * V + v) * 12;
         float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
         bool front = true;
@@ -188,8 +192,10 @@ k_brick_gate(const float *__restrict__ proj, const Coords coords, int *__restric
         used += chunks << 6;
         chunks_all += chunks;
         max_stride = stride > max_stride ? stride : max_stride;
+        used_max = used > used_max ? used : used_max;
+        chunks_max = chunks_all > chunks_max ? chunks_all : chunks_max;
     }
-    const bool fits = used <= g.cap_slots && chunks_all <= g.max_chunks && max_stride + 2 <= kZeroSlots;
+    const bool fits = used_max <= g.cap_slots && chunks_max <= g.max_chunks && max_stride + 2 <= kZeroSlots;
     if (!fits) atomicAdd(count, 1);
 }
 
