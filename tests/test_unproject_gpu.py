@@ -141,10 +141,12 @@ def test_forward_and_backward_vs_oracle(shape, mode, gpu):
     dict(B=1, V=2, C=12, H=32, W=32, vol=(4, 8, 32)),         # odd number of quads
     dict(B=1, V=4, C=8, H=320, W=320, vol=(4, 8, 32)),        # huge maps: the brick's taps overflow the LDS window -> global fallback
     dict(B=1, V=4, C=16, H=12, W=12, vol=(8, 8, 32)),         # tiny maps: most taps fall outside the image (zero padding)
-    dict(B=2, V=8, C=16, H=24, W=24, vol=(8, 8, 32)),         # 8 views: 512-thread bricks (4 x 4 x 32), 256 VGPRs per lane; 2 496 slots
-    dict(B=1, V=8, C=8, H=16, W=16, vol=(4, 4, 64)),          # 8 views, one brick column, two z bricks
-    dict(B=2, V=8, C=16, H=32, W=32, vol=(16, 16, 32)),       # 8 views, 32 bricks per sample
-    dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views, windows overflow (8 000 slots): slow path
+    dict(B=2, V=8, C=16, H=24, W=24, vol=(8, 8, 32)),         # 8 views, y % 8 == 0: 1024 threads, 4 x 8 x 32 bricks, two view groups
+    dict(B=1, V=8, C=8, H=16, W=16, vol=(4, 4, 64)),          # 8 views, y % 8 != 0: 512-thread bricks (4 x 4 x 32), two z bricks
+    dict(B=2, V=8, C=16, H=32, W=32, vol=(16, 16, 32)),       # 8 views, 16 bricks per sample
+    dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views, group windows of ~4 000 slots: still the 2-deep ring
+    dict(B=1, V=8, C=8, H=200, W=200, vol=(4, 8, 32)),        # 8 views, huge maps: the group windows overflow -> out-of-line global path
+    dict(B=1, V=8, C=8, H=200, W=200, vol=(4, 4, 32)),        # ... and the same for the 512-thread form
 ])
 @pytest.mark.parametrize("mode", MODES)
 def test_brick_variant_vs_oracle(shape, mode, gpu):
