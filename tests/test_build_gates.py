@@ -1,0 +1,40 @@
+"""The two build gates of csrc/Makefile (no GPU needed): check_resources.py rejects scratch in the kernels that wait on hand-counted
+vmcnt, check_loops.py rejects scratch inside the tap-reading loops of k_fwd_brick_groups."""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "multiviewhmr_amd", "csrc")
+
+
+def _run(script, path):
+    return subprocess.run([sys.executable, os.path.join(CSRC, script), path], capture_output=True, text=True)
+
+
+def test_check_resources_flags_scratch_in_the_counted_kernels(tmp_path):
+    remark = "x.hip:1:1: remark: Function Name: %s [-Rpass-analysis=kernel-resource-usage]\nx.hip:1:1: remark:     ScratchSize [bytes/lane]: %d [-Rpass-analysis=kernel-resource-usage]\n"
+    ok = tmp_path / "ok.txt"
+    ok.write_text(remark % ("_ZN5mvhmr11k_fwd_brickILi0ELi4ELi1024EfLi2EEEv", 0) + remark % ("_ZN5mvhmr11k_bwd_brickILi0ELi4ELi1024EfLi16EEEv", 452)
+                  + remark % ("_ZN5mvhmr18k_fwd_brick_groupsILi0ELi8EfEEv", 372))
+    assert _run("check_resources.py", str(ok)).returncode == 0            # backward: vmcnt(0) only; groups: checked on the asm instead
+    bad = tmp_path / "bad.txt"
+    bad.write_text(remark % ("_ZN5mvhmr11k_fwd_brickILi0ELi4ELi1024EfLi2EEEv", 80))
+    r = _run("check_resources.py", str(bad))
+    assert r.returncode == 1 and "scratch" in r.stderr
+
+
+def test_check_loops_flags_scratch_next_to_the_tap_reads(tmp_path):
+    head = "_ZN5mvhmr18k_fwd_brick_groupsILi0ELi8EfEEvPK:\n"
+    cold = ".LBB3_152:\n\tscratch_store_dword off, v1, off\n\tds_read_b128 v[0:3], v9\n"                      # not a loop block
+    loop_ok = ".LBB3_232:                              ;   in Loop: Header=BB3_232 Depth=1\n\tds_read_b128 v[0:3], v9\n\tv_mul_f32_e32 v0, v0, v7\n"
+    loop_bad = ".LBB3_244:                              ;   in Loop: Header=BB3_232 Depth=1\n\tds_read_b128 v[0:3], v9\n\tscratch_load_dword v7, off, off offset:40\n"
+    other_loop = ".LBB3_300:                              ;   in Loop: Header=BB3_300 Depth=1\n\tscratch_load_dword v7, off, off\n\tglobal_load_dwordx4 v[0:3], v[4:5], off\n"
+    tail = ".Lfunc_end3:\n"
+    ok = tmp_path / "ok.s"
+    ok.write_text(head + cold + loop_ok + other_loop + tail)               # the slow path's loop (no tap reads) may spill
+    assert _run("check_loops.py", str(ok)).returncode == 0
+    bad = tmp_path / "bad.s"
+    bad.write_text(head + cold + loop_ok + loop_bad + tail)
+    r = _run("check_loops.py", str(bad))
+    assert r.returncode == 1 and ".LBB3_244" in r.stderr
