@@ -74,6 +74,9 @@ def spawn_ranks(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
+    # ROCm's legacy IPC handles need a driver feature this pool's hosts lack (dmabuf IPC only): with the legacy mode on, RCCL's
+    # intra-node transport setup fails in hipIpcGetMemHandle ("invalid argument").  The image exports this already; it is pinned
+    # here so that a child started from a scrubbed environment still initialises RCCL.  Nothing on the data path depends on it.
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
     res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -331,7 +334,8 @@ def main():
         elapsed = float(t.item())
     ms_step = elapsed / a.steps * 1e3
     k_layout = float(np.mean([ev[3 * i].elapsed_time(ev[3 * i + 1]) for i in range(a.steps)]))
-    k_main = float(np.mean([ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(a.steps)]))
+    k_all = [ev[3 * i + 1].elapsed_time(ev[3 * i + 2]) for i in range(a.steps)]
+    k_main = float(np.mean(k_all))
 
     voxel_views = B * N * V * world
     value = voxel_views / (elapsed / a.steps) / 1e6
@@ -351,7 +355,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                      "kernel": "k_fwd_brick" if variant == 2 else "k_fwd_gather", "kernel_ms": round(k_main, 4),
-                     "layout_pass_ms": round(k_layout, 4), "algorithmic_bytes": alg_bytes,
+                     "kernel_ms_min": round(float(np.min(k_all)), 4), "layout_pass_ms": round(k_layout, 4), "algorithmic_bytes": alg_bytes,
                      "step_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
 
@@ -406,6 +410,9 @@ def main():
                 if tj.get("workload_key") == "%d-%d-%d-%d-%d-%s" % (S, C, V, HW, B, a.dtype):
                     result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
                     result["roofline"]["traffic_source"] = "replayed from %s (separate rocprofv3 --pmc passes, not this run)" % os.path.relpath(traffic, ROOT)
+                    if "backward" in result and "backward" in tj:
+                        result["backward"]["traffic"] = tj["backward"].get("hbm_bytes_per_launch")
+                        result["backward"]["traffic_source"] = result["roofline"]["traffic_source"]
             except Exception:
                 pass
         inside, invalid = frustum_stats(P_np[0], coords_np[0], HW, HW)

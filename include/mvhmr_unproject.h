@@ -60,12 +60,14 @@ typedef enum mvhmr_layout_t {
                                skips the layout pass (e.g. a channels_last 1x1 conv upstream) */
     MVHMR_LAYOUT_QUAD = 2   /* (B,V,C/4,Wf,Hf,4) fp32 whatever feat_dtype -- column-major "quad-planar": a pixel's 4 channels
                                are 16 contiguous bytes and a pixel COLUMN is one contiguous run, which is what the brick
-                               forward stages into LDS (tall narrow tap windows); only produced by
-                               mvhmr_convert_features (C % 4 == 0); forward only */
+                               forward stages into LDS (tall narrow tap windows); produced by mvhmr_convert_features and by
+                               mvhmr_conv1x1_to_quad (C % 4 == 0).  Forward and backward accept it; the backward then writes
+                               grad_features PLANAR (B,V,C,Hf,Wf).  With MVHMR_VARIANT_AUTO the geometry gate decides on the
+                               device as for planar input (the gather side converts the copy to channels-last first) */
 } mvhmr_layout_t;
 
 /* kernel selection; AUTO picks the fastest applicable one.  The others exist for tests and profiling.
- * AUTO with planar features of a shape both variants serve decides ON THE DEVICE (cameras and voxel pitch decide whether
+ * AUTO with planar or quad-planar features of a shape both variants serve decides ON THE DEVICE (cameras and voxel pitch decide whether
  * the brick variant's LDS windows fit): both variants are launched behind a gate and one of them runs; stream-ordered, no
  * host synchronisation.  mvhmr_unproject_selected_variant reports the variant AUTO prefers for the shape. */
 typedef enum mvhmr_variant_t {
@@ -96,6 +98,10 @@ typedef struct mvhmr_unproject_desc {
     int32_t feat_layout; /* mvhmr_layout_t                      */
     int32_t variant;     /* mvhmr_variant_t                     */
 } mvhmr_unproject_desc;
+
+/* 1 when mvhmr_unproject_backward[_cuboid] serves this descriptor (layout x variant x shape), else 0: lets set-up code choose a
+ * route before any tensor exists (the forward's counterpart is mvhmr_unproject_selected_variant > 0). */
+int mvhmr_unproject_backward_supported(const mvhmr_unproject_desc *desc);
 
 /* Bytes of device scratch forward / backward need for this problem (0 is possible). */
 size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc);
@@ -169,8 +175,9 @@ int mvhmr_convert_features(const mvhmr_unproject_desc *desc, const void *feature
  * process_feature (the 1x1 conv in front of the un-projection, models/aggregation.py:108-110,189-191) fused with the layout pass:
  *     y[m, co, p] = sum_ci weight[co, ci] * x[m, ci, p] + bias[co]          m = (b, v),  p = (y, x)
  * computed as an fp32 MFMA GEMM whose epilogue writes dst in MVHMR_LAYOUT_QUAD (n_maps, c_out/4, Wf, Hf, 4) -- feed it to
- * mvhmr_unproject_forward[_cuboid] with desc->feat_layout = MVHMR_LAYOUT_QUAD (brick variant) and the planar conv output and the
- * layout pass never exist.  mvhmr_unproject_backward[_cuboid] accepts the same MVHMR_LAYOUT_QUAD features (brick backward) and
+ * mvhmr_unproject_forward[_cuboid] with desc->feat_layout = MVHMR_LAYOUT_QUAD and the planar conv output and the layout pass
+ * never exist (variant AUTO: the brick kernels read the copy as it is; when the geometry gate picks the gather kernels they get a
+ * channels-last conversion of it).  mvhmr_unproject_backward[_cuboid] accepts the same MVHMR_LAYOUT_QUAD features and
  * then writes grad_features in the PLANAR layout (n_maps, c_out, Hf, Wf), which is what the conv's own backward consumes.
  *   x (n_maps, c_in, Hf, Wf) fp32, weight (c_out, c_in) fp32 (nn.Conv2d's (c_out, c_in, 1, 1)), bias (c_out) fp32 or null.
  * Shapes: c_in % 16 == 0, c_out % 128 == 0, Hf % 4 == 0, Wf % 32 == 0 (mvhmr_conv1x1_to_quad_supported), else MVHMR_ERR_UNSUPPORTED.

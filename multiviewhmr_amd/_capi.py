@@ -23,6 +23,7 @@ EXPORTS = (
     "mvhmr_unproject_query_variant", "mvhmr_internal_lds_cache_key",
     "mvhmr_unproject_forward_cuboid", "mvhmr_unproject_backward_cuboid",
     "mvhmr_conv1x1_to_quad", "mvhmr_conv1x1_to_quad_supported", "mvhmr_conv1x1_planar", "mvhmr_conv1x1_planar_supported", "mvhmr_conv1x1_wgrad", "mvhmr_conv1x1_wgrad_supported", "mvhmr_unproject_query_variant_cuboid",
+    "mvhmr_unproject_backward_supported",
 )
 
 
@@ -57,6 +58,8 @@ def lib():
     L.mvhmr_unproject_backward_workspace_bytes.argtypes = [dp]
     L.mvhmr_unproject_selected_variant.restype = ctypes.c_int
     L.mvhmr_unproject_selected_variant.argtypes = [dp]
+    L.mvhmr_unproject_backward_supported.restype = ctypes.c_int
+    L.mvhmr_unproject_backward_supported.argtypes = [dp]
     L.mvhmr_unproject_query_variant.restype = ctypes.c_int
     L.mvhmr_unproject_query_variant.argtypes = [dp, vp, vp, vp]
     L.mvhmr_unproject_forward.restype = ctypes.c_int

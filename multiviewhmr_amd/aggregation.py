@@ -259,8 +259,11 @@ def feature_level_projections(cameras, images_shape, features_shape):
 class _FusedAggregate(torch.autograd.Function):
     """process_feature (1x1 conv) + un-projection with the conv output living only in the quad-planar layout the brick forward
     stages (mvhmr_conv1x1_to_quad + mvhmr_unproject_forward_cuboid on MVHMR_LAYOUT_QUAD): the planar (B,V,C,Hf,Wf) conv output
-    and the layout pass over it are never written.  Backward: the brick backward gives the gradient w.r.t.
-    the conv output in the planar layout; weight / bias / input gradients are three GEMMs on it."""
+    and the layout pass over it are never written.  The un-projection runs with MVHMR_VARIANT_AUTO: the
+    geometry gate decides brick / gather on the device for THIS call's cameras and pose (the gather side converts the copy to
+    channels-last first), forward and backward each for their own bricks -- no cached decision, no host synchronisation.
+    Backward: the un-projection backward gives the gradient w.r.t. the conv output in the planar layout; weight / bias / input
+    gradients are three GEMMs on it."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, proj, rot, center, position, sides, vol, method):
@@ -276,10 +279,11 @@ class _FusedAggregate(torch.autograd.Function):
             quad = torch.empty(B * V * Cout * Hf * Wf, dtype=torch.float32, device=dev)
             _capi.check(L.mvhmr_conv1x1_to_quad(_ptr(x), _ptr(w2), _ptr(bias) if bias is not None else ctypes.c_void_p(0), _ptr(quad),
                                                 B * V, Cin, Cout, Hf, Wf, _stream(dev)))
-            desc = _make_desc(torch.empty((B, V, Cout, Hf, Wf), dtype=torch.float32, device="meta"), vol, method, torch.float32, _capi.LAYOUT_QUAD, _capi.VARIANT["brick"])
+            desc = _make_desc(torch.empty((B, V, Cout, Hf, Wf), dtype=torch.float32, device="meta"), vol, method, torch.float32, _capi.LAYOUT_QUAD, _capi.VARIANT["auto"])
             out = torch.empty((B, Cout) + tuple(vol), dtype=torch.float32, device=dev)
+            ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), dev)
             _capi.check(L.mvhmr_unproject_forward_cuboid(ctypes.byref(desc), _ptr(quad), _ptr(proj), _ptr(rot), _ptr(center), pos, sid,
-                                                         _ptr(out), ctypes.c_void_p(0), 0, _stream(dev)))
+                                                         _ptr(out), wsp, 0 if ws is None else ws.numel(), _stream(dev)))
         ctx.save_for_backward(x, w2, quad, proj, rot, center)
         ctx.desc, ctx.pos, ctx.sid, ctx.has_bias, ctx.wshape = desc, pos, sid, bias is not None, tuple(weight.shape)
         return out
@@ -368,8 +372,7 @@ class VolumeGenerator(nn.Module):
         self.use_triangulation = use_triangulation
         self.kind = kind
         self.dataset = dataset
-        self.fused_conv = True            # 1x1 conv + layout pass as one MFMA GEMM where the brick kernels run (see _fused_path_applies)
-        self._fused_cache = {}
+        self.fused_conv = True            # 1x1 conv + layout pass as one MFMA GEMM wherever its shapes allow (see _fused_path_applies)
         self.to(device)
 
     # -- geometry the reference builds inside forward(); split out so it can be checked without a GPU
@@ -437,18 +440,20 @@ class VolumeGenerator(nn.Module):
         if 'cameras_packed' in batch:                                       # device tensors: no camera loop, no H2D copy
             proj = feature_level_projections_device(batch['cameras_packed'], images_shape, features_shape)
         else:
-            proj = torch.from_numpy(feature_level_projections(batch['cameras'], images_shape, features_shape)).to(device)
+            proj = torch.from_numpy(feature_level_projections(batch['cameras'], images_shape, features_shape))
+        # the kernels take raw device pointers: whatever device the packed cameras live on (a loader may pack them on the host)
+        proj = proj.to(device=device, dtype=torch.float32).contiguous()
         rots, centers = self.volume_pose(batch, proj_org, images_shape)
         cub = self.cuboid()
         S = self.volume_size
-        rots, centers = rots.to(device), centers.to(device)
+        rots = rots.to(device=device, dtype=torch.float32).contiguous()
+        centers = centers.to(device=device, dtype=torch.float32).contiguous()
 
-        if self._fused_path_applies(features, proj, rots, centers, cub, S):
+        if self._fused_path_applies(features, S):
             # 1x1 conv and layout pass in one MFMA GEMM, its output only ever exists in the layout the brick forward stages
             conv = self.process_feature[0]
-            return _FusedAggregate.apply(features, conv.weight, conv.bias, proj.contiguous(), rots.to(torch.float32).contiguous(),
-                                         centers.to(torch.float32).contiguous(), tuple(cub.position), tuple(cub.sides), (S, S, S),
-                                         _capi.AGG[self.aggregation_method])
+            return _FusedAggregate.apply(features, conv.weight, conv.bias, proj, rots, centers, tuple(cub.position), tuple(cub.sides),
+                                         (S, S, S), _capi.AGG[self.aggregation_method])
 
         features = features.view(-1, *features.shape[2:])
         features = self.process_feature(features)
@@ -457,32 +462,25 @@ class VolumeGenerator(nn.Module):
         return unprojection_cuboid(features, proj, rots, centers, cub.position, cub.sides, (S, S, S),
                                    aggregation_method=self.aggregation_method)
 
-    def _fused_path_applies(self, features, proj, rots, centers, cub, S):
-        """The fused conv writes the brick kernels' layout, so it is used only where the brick kernels run: fp32, shapes both
-        kernels take, and a geometry for which the device-side gate picks the brick variant.  That last question costs one
-        synchronous query the FIRST time a (volume, map, view, channel) shape is seen and is cached after that: the voxel pitch in
-        pixels is a property of the data set's camera rig and of the configuration, not of the batch."""
-        if not self.fused_conv or features.dtype != torch.float32 or not features.is_cuda or self.aggregation_method not in _METHODS:
+    def _fused_path_applies(self, features, S):
+        """The fused conv writes the quad-planar layout, which the un-projection consumes for every geometry (brick kernels as it
+        is, gather kernels through one conversion; the device-side gate picks per call).  So only shapes, dtypes and devices
+        decide here -- checked on every call, nothing cached: fp32 everywhere, conv parameters on the features' device, a shape the
+        fused GEMM takes and one whose quad-planar copy the un-projection (forward and backward) accepts."""
+        if not self.fused_conv or not features.is_cuda or features.dtype != torch.float32 or self.aggregation_method not in _METHODS:
+            return False
+        conv = self.process_feature[0]
+        params = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
+        if any(t.dtype != torch.float32 or t.device != features.device for t in params):
             return False
         B, V, Cin, Hf, Wf = features.shape
-        conv = self.process_feature[0]
         Cout = conv.out_channels
         L = _capi.lib()
         if not L.mvhmr_conv1x1_to_quad_supported(Cin, Cout, Hf, Wf):
             return False
-        key = (S, Hf, Wf, V, Cout, self.aggregation_method, float(self.cuboid_side))
-        hit = self._fused_cache.get(key)
-        if hit is None:
-            meta = torch.empty((B, V, Cout, Hf, Wf), dtype=torch.float32, device="meta")
-            desc = _make_desc(meta, (S, S, S), _capi.AGG[self.aggregation_method], torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["auto"])
-            pos = (ctypes.c_double * 3)(*[float(v) for v in cub.position])
-            sid = (ctypes.c_double * 3)(*[float(v) for v in cub.sides])
-            with torch.cuda.device(features.device):
-                got = L.mvhmr_unproject_query_variant_cuboid(ctypes.byref(desc), _ptr(proj.contiguous()), _ptr(rots.to(torch.float32).contiguous()),
-                                                             _ptr(centers.to(torch.float32).contiguous()), pos, sid, _stream(features.device))
-            hit = got == _capi.VARIANT["brick"]
-            self._fused_cache[key] = hit
-        return hit
+        meta = torch.empty((B, V, Cout, Hf, Wf), dtype=torch.float32, device="meta")
+        desc = _make_desc(meta, (S, S, S), _capi.AGG[self.aggregation_method], torch.float32, _capi.LAYOUT_QUAD, _capi.VARIANT["auto"])
+        return L.mvhmr_unproject_selected_variant(ctypes.byref(desc)) > 0 and L.mvhmr_unproject_backward_supported(ctypes.byref(desc)) == 1
 
 
 def build_volume_generator(cfg):

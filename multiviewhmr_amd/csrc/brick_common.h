@@ -1,4 +1,4 @@
-// Helpers shared by the brick kernels (forward: unproject_brick.hip, backward: unproject_brick_bwd.hip).
+// Helpers shared by the brick kernels (forward: brick_fwd_kernel.h / brick_fwd_groups.h, backward: unproject_brick_bwd.hip).
 #pragma once
 #include <type_traits>
 #include "device_common.h"
@@ -38,6 +38,12 @@ __device__ __forceinline__ void glds16(const void *base, unsigned voff, unsigned
                  : "=&s"(keep)
                  : "v"(voff), "s"(base), "s"(lds_dst)
                  : "memory");
+}
+
+// same, m0 left clobbered (declared): no save / restore around every piece
+__device__ __forceinline__ void glds16_m0(const void *base, unsigned voff, unsigned lds_dst)
+{
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
 }
 
 __device__ __forceinline__ f32x4 lds_tap(const unsigned char *smem, int addr)

@@ -83,7 +83,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     fwd_lane_voxel(lane, dcol, zin);
     const int col = wave * 2 + dcol;
     const int vx = kx * kBX + (col & 3), vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
-    const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_supported)
+    const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_fwd_supported)
     float w00[VT], w01[VT], w10[VT], w11[VT];
     int tx[VT], ty[VT];
     unsigned valid = 0;

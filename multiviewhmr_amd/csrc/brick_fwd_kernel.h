@@ -27,6 +27,14 @@
 
 namespace mvhmr {
 
+// Timing-only ablations for scripts/exp (never defined in the product build): bit 0 conflict-free fake tap addresses, 1 no tap reads,
+// 2 no LDS-DMA, 3 no stores, 4 no transcendentals, 5 no transpose, 6 no per-quad barrier, 7 no aggregate, 8 no wait for the DMA,
+// 9 LDS-DMA without the m0 save / restore
+#ifndef MVHMR_EXP
+#define MVHMR_EXP 0
+#endif
+constexpr int kExp = MVHMR_EXP;
+
 // lane = 32 g + 16 h + 4 a + b  ->  column h of the wave's two (x-adjacent) columns, z = 16 g + 4 b + a
 __device__ __forceinline__ void fwd_lane_voxel(int lane, int &dcol, int &zin)
 {
@@ -58,6 +66,32 @@ __device__ __forceinline__ void stride4_transpose(float (&r)[4], int lane)
         const float n2 = dpp_into<ROR8, 0x3>(r[2], x), n0 = dpp_into<ROR8, 0xC>(r[0], x);
         const float n3 = dpp_into<ROR8, 0x3>(r[3], y), n1 = dpp_into<ROR8, 0xC>(r[1], y);
         r[0] = n0; r[1] = n1; r[2] = n2; r[3] = n3;
+    }
+}
+
+// aggregate<> behind the timing-only ablations (kExp == 0: exactly aggregate<>)
+template <int METHOD, int VT>
+__device__ __forceinline__ float fwd_aggregate(const float (&s)[VT])
+{
+    if constexpr (kExp & 128) {
+        float r = s[0];
+#pragma unroll
+        for (int v = 1; v < VT; ++v) r += s[v];
+        return r;
+    } else if constexpr ((kExp & 16) && METHOD == AGG_SOFTMAX && VT == 4) {
+        const float m = vmax(vmax3(s[0], s[1], s[2]), s[3]);
+        const float nm = -m * 1.4426950408889634f;
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            float e = fmaf(s[v], 1.4426950408889634f, nm);
+            e = fmaf(e, 0.5f, 1.f);                                              // stands in for v_exp_f32
+            den += e;
+            num = fmaf(e, s[v], num);
+        }
+        return num * fmaf(den, 0.25f, 1.f);                                      // stands in for v_rcp_f32
+    } else {
+        return aggregate<METHOD, VT>(s);
     }
 }
 
@@ -120,7 +154,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
 #pragma unroll
         for (int u = 0; u < NVOX; ++u) {
             const int vx = kx * BXK + (col & 3) + kBX * u;
-            vox[u] = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_supported)
+            vox[u] = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_fwd_supported)
             float c0, c1, c2;
             voxel_xyz(coords, b, N, vox[u], c0, c1, c2);
 #pragma unroll
@@ -188,6 +222,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 const bool ok = (valid >> (u * VT + v)) & 1u;
                 const int s0 = slot0[v] + (tx[u][v] - wx0[v]) * ws[v] + (ty[u][v] - wy0[v]);
                 a0[u][v] = ok ? kZeroBytes + s0 * 16 : 0;
+                if constexpr (kExp & 1) a0[u][v] = kZeroBytes + (lane + 64 * v + 256 * u) * 16;
             }
         }
         // ---- DMA chunks of this wave: chunk c covers 64 consecutive slots of one view's window
@@ -223,7 +258,10 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             const int boff = ring(q);
 #pragma unroll
             for (int rr = 0; rr < MC; ++rr)
-                if (l_dst[rr] >= 0) glds16(src, g_off[rr], lds_base + (unsigned)uniform(l_dst[rr] + boff));
+                if (l_dst[rr] >= 0 && !(kExp & 4)) {
+                    if constexpr (kExp & 512) glds16_m0(src, g_off[rr], lds_base + (unsigned)uniform(l_dst[rr] + boff));
+                    else glds16(src, g_off[rr], lds_base + (unsigned)uniform(l_dst[rr] + boff));
+                }
         };
 
         // ---- stores: lane 4a+b (+16h+32g) writes channel a, z = 16g + 4b .. 4b+3 of its column
@@ -237,8 +275,10 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         }
         auto store_quad = [&](int q, int u, float (&res)[4]) __attribute__((always_inline)) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
-            stride4_transpose(res, lane);
-            if constexpr (OSZ == 4) {
+            if constexpr (!(kExp & 32)) stride4_transpose(res, lane);
+            if constexpr (kExp & 8) {
+                asm volatile("" :: "v"(res[0]), "v"(res[1]), "v"(res[2]), "v"(res[3]), "s"(rs));
+            } else if constexpr (OSZ == 4) {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
                                  __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
@@ -255,6 +295,13 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         f32x4 T[2][4];
         auto read_view = [&](int q, int u, int v, int set) __attribute__((always_inline)) {
             const int base = a0[u][v] + ring(q), far = base + ws16[v];
+            if constexpr (kExp & 2) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(T[set][t].v[i]) : "v"(base), "v"(far));
+                return;
+            }
             T[set][0] = lds_tap(smem, base); T[set][2] = lds_tap(smem, base + 16);
             T[set][1] = lds_tap(smem, far); T[set][3] = lds_tap(smem, far + 16);
         };
@@ -277,8 +324,8 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // PAR: which of sq / sp receives the samples of job u = 0 (alternates per quad when NVOX is odd)
         auto quad_iter = [&](int q, auto par_tag) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value;
-            if (q < 2 || q + 1 >= nq) wait_vmcnt(0); else wait_vmcnt(ncw);
-            bare_barrier();
+            if constexpr (!(kExp & 256)) { if (q < 2 || q + 1 >= nq) wait_vmcnt(0); else wait_vmcnt(ncw); }
+            if constexpr (!(kExp & 64)) bare_barrier();
             if (nb == 2 && q + 1 < nq) dma(q + 1);
 #pragma unroll
             for (int u = 0; u < NVOX; ++u) {
@@ -290,14 +337,14 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 read_view(q, u, 0, 0);
                 if constexpr (VT > 1) read_view(q, u, 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                res[0] = aggregate<METHOD, VT>(prev[0]);
-                res[1] = aggregate<METHOD, VT>(prev[1]);
+                res[0] = fwd_aggregate<METHOD, VT>(prev[0]);
+                res[1] = fwd_aggregate<METHOD, VT>(prev[1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int v = 0; v < VT; ++v) {
                     if (v == (VT + 1) / 2) {
-                        res[2] = aggregate<METHOD, VT>(prev[2]);
-                        res[3] = aggregate<METHOD, VT>(prev[3]);
+                        res[2] = fwd_aggregate<METHOD, VT>(prev[2]);
+                        res[3] = fwd_aggregate<METHOD, VT>(prev[3]);
                         if (st) store_quad(u > 0 ? q : q - 1, u > 0 ? u - 1 : NVOX - 1, res);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -324,7 +371,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // the last job: (nq - 1, NVOX - 1)
         const bool last_in_sp = ((NVOX & 1) ? nq - 1 : NVOX - 1) & 1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) res[c] = last_in_sp ? aggregate<METHOD, VT>(sp[c]) : aggregate<METHOD, VT>(sq[c]);
+        for (int c = 0; c < 4; ++c) res[c] = last_in_sp ? fwd_aggregate<METHOD, VT>(sp[c]) : fwd_aggregate<METHOD, VT>(sq[c]);
         store_quad(nq - 1, NVOX - 1, res);
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (clamped taps, zero weights outside)

@@ -89,11 +89,11 @@ size_t feat_elem(const Problem &p) { return p.feat_f16 ? 2 : 4; }
 size_t featT_bytes(const Problem &p) { return align_up((size_t)p.B * p.V * p.H * p.W * p.C4 * feat_elem(p)); }
 size_t gradT_bytes(const Problem &p) { return align_up((size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float)); }
 
-// which kernel runs: the layout the caller hands over decides when it is not the reference's planar one
+// which kernel runs: channels-last input feeds the gather kernels; quad-planar input (the fused 1x1 conv's output) the brick kernels,
+// or -- through one more layout pass -- the gather kernels when the caller or the shape asks for them
 int pick_variant(const mvhmr_unproject_desc *d, const Problem &p)
 {
     if (d->feat_layout == MVHMR_LAYOUT_BVHWC) return MVHMR_VARIANT_GATHER;
-    if (d->feat_layout == MVHMR_LAYOUT_QUAD) return MVHMR_VARIANT_BRICK;
     if (d->variant != MVHMR_VARIANT_AUTO) return d->variant;
     return brick_fwd_supported(p) ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
 }
@@ -103,6 +103,8 @@ int variant_conflict(const mvhmr_unproject_desc *d, const Problem &p, int varian
     if (variant == MVHMR_VARIANT_BRICK && !brick_fwd_supported(p)) return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype");
     if (d->variant != MVHMR_VARIANT_AUTO && d->variant != variant)
         return fail(MVHMR_ERR_UNSUPPORTED, "feature layout %d cannot feed kernel variant %d", d->feat_layout, d->variant);
+    if (variant == MVHMR_VARIANT_GATHER && d->feat_layout == MVHMR_LAYOUT_QUAD && !quad_to_channels_last_supported(p))
+        return fail(MVHMR_ERR_UNSUPPORTED, "quad-planar features of this shape cannot feed the gather kernels (C <= 4092, B * V <= 65535)");
     return MVHMR_OK;
 }
 
@@ -114,18 +116,25 @@ bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->
 // (17 ms against 104 ms at the north-star size: profiles/r01_final_pmc.txt).  variant = gather keeps the gather backward.
 bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
 {
+    if (d->feat_layout == MVHMR_LAYOUT_QUAD && p.feat_f16) return false;        // the quad copy is fp32; mixed storage goes through the gather backward
     return (d->feat_layout == MVHMR_LAYOUT_BVCHW || d->feat_layout == MVHMR_LAYOUT_QUAD) && d->variant != MVHMR_VARIANT_GATHER && brick_bwd_supported(p);
 }
 
 // AUTO on planar input, for a shape both variants serve: the variant is chosen on the device from the geometry (gate.h).
+// Quad-planar input is gated the same way (the gather side then converts it to channels-last first), so a caller that keeps
+// only the fused conv's copy never pins a variant the geometry does not suit.
+bool gateable_layout(const mvhmr_unproject_desc *d, const Problem &p)
+{
+    return d->feat_layout == MVHMR_LAYOUT_BVCHW || (d->feat_layout == MVHMR_LAYOUT_QUAD && quad_to_channels_last_supported(p));
+}
 bool geometry_gated(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    return d->variant == MVHMR_VARIANT_AUTO && d->feat_layout == MVHMR_LAYOUT_BVCHW && brick_fwd_supported(p);
+    return d->variant == MVHMR_VARIANT_AUTO && gateable_layout(d, p) && brick_fwd_supported(p);
 }
 // the backward has its own bricks and windows, hence its own gate
 bool geometry_gated_bwd(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    return d->variant == MVHMR_VARIANT_AUTO && d->feat_layout == MVHMR_LAYOUT_BVCHW && brick_bwd_supported(p);
+    return d->variant == MVHMR_VARIANT_AUTO && gateable_layout(d, p) && brick_bwd_supported(p);
 }
 constexpr size_t kGateBytes = 256;
 // the converted feature copy of a gated launch: channels-last in the feature dtype or quad-planar fp32, whichever is larger
@@ -234,12 +243,23 @@ int mvhmr_unproject_query_variant(const mvhmr_unproject_desc *desc, const float 
     return host <= brick_count(p, g) / 8 ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
 }
 
+int mvhmr_unproject_backward_supported(const mvhmr_unproject_desc *desc)
+{
+    Problem p;
+    if (check_desc(desc, &p) != MVHMR_OK) return 0;
+    if (desc->variant == MVHMR_VARIANT_BRICK && !bwd_uses_brick(desc, p)) return 0;
+    if (desc->feat_layout == MVHMR_LAYOUT_QUAD && !bwd_uses_brick(desc, p) && !quad_to_channels_last_supported(p)) return 0;
+    if (desc->feat_layout == MVHMR_LAYOUT_QUAD && desc->variant == MVHMR_VARIANT_GATHER && !quad_to_channels_last_supported(p)) return 0;
+    return 1;
+}
+
 size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc)
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
-    if (desc->feat_layout != MVHMR_LAYOUT_BVCHW) return 0;
+    if (desc->feat_layout == MVHMR_LAYOUT_BVHWC) return 0;
     if (geometry_gated(desc, p)) return conv_bytes(p) + kGateBytes;   // one converted copy (either layout) + the gate counter
+    if (desc->feat_layout == MVHMR_LAYOUT_QUAD) return pick_variant(desc, p) == MVHMR_VARIANT_BRICK ? 0 : featT_bytes(p);
     return pick_variant(desc, p) == MVHMR_VARIANT_BRICK ? brick_workspace_bytes(p) : featT_bytes(p);
 }
 
@@ -249,7 +269,7 @@ size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
     if (geometry_gated_bwd(desc, p) && bwd_uses_brick(desc, p)) return conv_bytes(p) + gradT_bytes(p) + kGateBytes;
     if (bwd_uses_brick(desc, p)) return brick_workspace_bytes(p) + gradT_bytes(p);
-    size_t need = desc->feat_layout == MVHMR_LAYOUT_BVCHW ? featT_bytes(p) : 0;
+    size_t need = desc->feat_layout != MVHMR_LAYOUT_BVHWC ? featT_bytes(p) : 0;
     if (!grad_in_place(desc, p)) need += gradT_bytes(p);
     return need;
 }
@@ -271,11 +291,14 @@ static int forward_impl(const mvhmr_unproject_desc *desc, Problem &p, const void
         unsigned char *ws = static_cast<unsigned char *>(workspace);
         rc = arm_gate(p, ws + conv_bytes(p), proj, coords, brick_fwd_gate_geom(p), s);
         if (rc != MVHMR_OK) return rc;
-        rc = launched(launch_to_quad_planar_t(features, ws, p, s), "layout pass");
+        const bool quad = desc->feat_layout == MVHMR_LAYOUT_QUAD;
+        if (!quad) {
+            rc = launched(launch_to_quad_planar_t(features, ws, p, s), "layout pass");
+            if (rc != MVHMR_OK) return rc;
+        }
+        rc = launched(quad ? launch_quad_to_channels_last(features, ws, p, s) : launch_to_channels_last(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
-        rc = launched(launch_to_channels_last(features, ws, p, s), "layout pass");
-        if (rc != MVHMR_OK) return rc;
-        rc = launched(launch_fwd_brick(ws, proj, coords, out, p, s), "brick forward");
+        rc = launched(launch_fwd_brick(quad ? features : ws, proj, coords, out, p, s), "brick forward");
         if (rc != MVHMR_OK) return rc;
         return launched(launch_fwd_gather(ws, proj, coords, out, p, s), "gather forward");
     }
@@ -291,8 +314,9 @@ static int forward_impl(const mvhmr_unproject_desc *desc, Problem &p, const void
     }
 
     const void *featT = features;
-    if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) {
-        rc = launched(launch_to_channels_last(features, workspace, p, s), "layout pass");
+    if (desc->feat_layout != MVHMR_LAYOUT_BVHWC) {
+        rc = launched(desc->feat_layout == MVHMR_LAYOUT_QUAD ? launch_quad_to_channels_last(features, workspace, p, s)
+                                                             : launch_to_channels_last(features, workspace, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
         featT = workspace;
     }
@@ -328,8 +352,8 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
     int rc;
     if (!grad_out || !features || !proj || !grad_features)
         return fail(MVHMR_ERR_INVALID_ARGUMENT, "grad_out / features / proj / grad_features must be non-null");
-    if (desc->feat_layout == MVHMR_LAYOUT_QUAD && (!bwd_uses_brick(desc, p) || p.feat_f16))
-        return fail(MVHMR_ERR_UNSUPPORTED, "backward from quad-planar features needs the brick backward (fp32, one storage type, 2 / 4 / 8 views)");
+    if (desc->feat_layout == MVHMR_LAYOUT_QUAD && !bwd_uses_brick(desc, p) && !quad_to_channels_last_supported(p))
+        return fail(MVHMR_ERR_UNSUPPORTED, "backward from quad-planar features of this shape needs the brick backward (fp32, 2 / 4 / 8 views)");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     rc = check_ws(workspace, workspace_bytes, mvhmr_unproject_backward_workspace_bytes(desc));
     if (rc != MVHMR_OK) return rc;
@@ -341,9 +365,11 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
         float *acc = reinterpret_cast<float *>(ws + conv_bytes(p));               // quad-planar or channels-last accumulator
         rc = arm_gate(p, ws + conv_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_gate_geom(p), s);
         if (rc != MVHMR_OK) return rc;
-        rc = launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
+        const bool quad = desc->feat_layout == MVHMR_LAYOUT_QUAD;
+        rc = launched(quad ? launch_quad_transpose(features, ws, p.B * p.V * (p.C / 4), p.H, p.W, make_gate(p, true), s)
+                           : launch_to_quad_planar(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
-        rc = launched(launch_to_channels_last(features, ws, p, s), "layout pass");
+        rc = launched(quad ? launch_quad_to_channels_last(features, ws, p, s) : launch_to_channels_last(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
         hipError_t e = hipMemsetAsync(acc, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
         if (e != hipSuccess) return launched(e, "gradient clear");
@@ -358,7 +384,7 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
     if (bwd_uses_brick(desc, p)) {
         float *gradK = reinterpret_cast<float *>(ws + brick_workspace_bytes(p));
         rc = desc->feat_layout == MVHMR_LAYOUT_QUAD
-                 ? launched(launch_quad_transpose(features, ws, p.B * p.V * (p.C / 4), p.H, p.W, s), "layout pass")   // column-major copy -> row-major
+                 ? launched(launch_quad_transpose(features, ws, p.B * p.V * (p.C / 4), p.H, p.W, Gate{nullptr, 0, 1}, s), "layout pass")   // column-major copy -> row-major
                  : launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
         hipError_t e = hipMemsetAsync(gradK, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
@@ -368,8 +394,9 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
         return launched(launch_quad_grad_to_planar(gradK, grad_features, p, s), "gradient layout pass");
     }
     const void *featT = features;
-    if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) {
-        rc = launched(launch_to_channels_last(features, ws, p, s), "layout pass");
+    if (desc->feat_layout != MVHMR_LAYOUT_BVHWC) {
+        rc = launched(desc->feat_layout == MVHMR_LAYOUT_QUAD ? launch_quad_to_channels_last(features, ws, p, s) : launch_to_channels_last(features, ws, p, s),
+                      "layout pass");
         if (rc != MVHMR_OK) return rc;
         featT = ws;
         ws += featT_bytes(p);
@@ -381,7 +408,7 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
     if (e != hipSuccess) return launched(e, "gradient clear");
     rc = launched(launch_bwd_gather(grad_out, featT, proj, coords, gradT, p, s), "gather backward");
     if (rc != MVHMR_OK || in_place) return rc;
-    if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) return launched(launch_grad_to_planar(gradT, grad_features, p, s), "gradient layout pass");
+    if (desc->feat_layout != MVHMR_LAYOUT_BVHWC) return launched(launch_grad_to_planar(gradT, grad_features, p, s), "gradient layout pass");   // planar gradient for planar and quad-planar features alike
     return launched(launch_grad_cast(gradT, grad_features, p, s), "gradient cast");
 }
 

@@ -1,40 +1,102 @@
 #!/usr/bin/env python3
-"""Build gate for the brick forward kernels: the quad loops that run behind hand-counted `s_waitcnt vmcnt(N)` (the blocks with the
-ds_read_b128 tap reads) must not touch scratch -- the compiler follows a spill reload with `s_waitcnt vmcnt(0)`, which also waits for
-the LDS-DMA of the next ring item that was just requested (measured: the prefetch is gone).  k_fwd_brick is held to zero scratch by
-check_resources.py; k_fwd_brick_groups keeps a noinline slow path whose call frame is scratch outside the loop, so its loops are
-checked here on the device assembly (hipcc -save-temps)."""
+"""Build gate on the device assembly (hipcc -save-temps): the hot loops of the brick kernels must not touch scratch.
+
+  k_fwd_brick_groups  quad loops that run behind hand-counted `s_waitcnt vmcnt(N)` (the loops with the ds_read_b128 tap reads): the
+                      compiler follows a spill reload with `s_waitcnt vmcnt(0)`, which also waits for the LDS-DMA of the next ring
+                      item that was just requested (measured: the prefetch is gone).  Its noinline slow path keeps a scratch call
+                      frame outside the loop, so check_resources.py cannot hold the kernel to zero scratch.
+  k_bwd_brick         the quad loop with the ds_add_u32 accumulation: same reason (its counted wait_vmcnt(n_at) after the flush
+                      atomics assumes the atomics are the wave's youngest vector-memory operations), and the same noinline slow path.
+
+usage: check_loops.py <kernel-name-prefix>:<hot instruction> [...] -- file.s [...]
+A loop is every basic block that names the same `in Loop: Header=` (plus the header block itself).  Exits non-zero when a hot loop
+touches scratch, and also when a prefix matches no function or a matched prefix has no hot loop at all (a rename must not turn the
+gate off silently)."""
 import re
 import sys
 
-bad = []
-for path in sys.argv[1:]:
-    name, blk, in_loop, stats = None, None, False, {}
+
+def scan(path, rules):
+    """rules: {mangled-name substring: hot instruction} -> (violations, functions seen per rule, hot loops per rule)"""
+    bad, seen, hot = [], {k: 0 for k in rules}, {k: 0 for k in rules}
+    name, rule, loops, cur, label, fresh = None, None, {}, None, "", False
+
+    def close():
+        if name is None:
+            return
+        for header, (n_hot, n_scratch) in loops.items():
+            if n_hot:
+                hot[rule] += 1
+                if n_scratch:
+                    bad.append((name, header, n_scratch))
+
     for line in open(path):
         ls = line.strip()
-        m = re.match(r"^(_ZN5mvhmr18k_fwd_brick_groups\S*):", ls)
-        if m:
-            name = m.group(1)
+        m = re.match(r"^(_Z\S+):", ls)
+        if m and not ls.startswith(".L"):
+            close()
+            name, rule, loops, cur = None, None, {}, None
+            for k in rules:
+                if k in m.group(1):
+                    name, rule = m.group(1), k
+                    seen[k] += 1
             continue
         if ls.startswith(".Lfunc_end"):
-            name = None
+            close()
+            name, rule, loops, cur = None, None, {}, None
             continue
         if name is None:
             continue
-        m = re.match(r"^(\.LBB\d+_\d+):", ls)
-        if m:
-            blk = (name, m.group(1))
-            in_loop = "in Loop" in ls or "Loop Header" in ls
-            stats[blk] = [in_loop, 0, 0]
+        m = re.match(r"^\.L(BB\d+_\d+):", ls) or re.match(r"^; %bb\.(\d+):", ls)
+        if m:                                                                    # a new basic block (labelled or fall-through)
+            label, cur, fresh = m.group(1), None, True
+        if ls.startswith(";") or m:                                              # the loop note sits on the label line or on the comment line after it
+            if fresh:
+                h = re.search(r"in Loop: Header=(BB\d+_\d+)", ls)
+                if h:
+                    cur = h.group(1)
+                elif "Loop Header" in ls and label.startswith("BB"):
+                    cur = label
+                if cur is not None:
+                    loops.setdefault(cur, [0, 0])
             continue
-        if blk and ls and not ls.startswith(";"):
-            if "ds_read_b128" in ls:
-                stats[blk][1] += 1
+        fresh = False
+        if cur is not None and ls and not ls.startswith(";"):
+            if ls.startswith(rules[rule]):
+                loops[cur][0] += 1
             if ls.startswith("scratch_"):
-                stats[blk][2] += 1
-    for (kname, b), (loop, reads, scratch) in stats.items():
-        if loop and reads and scratch:
-            bad.append((kname, b, scratch))
-for kname, b, scratch in bad:
-    sys.stderr.write("loop check: %s block %s has %d scratch accesses inside the quad loop\n" % (kname, b, scratch))
-sys.exit(1 if bad else 0)
+                loops[cur][1] += 1
+    close()
+    return bad, seen, hot
+
+
+def main(argv):
+    if "--" not in argv:
+        sys.stderr.write(__doc__)
+        return 2
+    i = argv.index("--")
+    rules = dict(a.split(":", 1) for a in argv[:i])
+    files = argv[i + 1:]
+    bad, seen, hot = [], {k: 0 for k in rules}, {k: 0 for k in rules}
+    for path in files:
+        b, s, h = scan(path, rules)
+        bad += b
+        for k in rules:
+            seen[k] += s[k]
+            hot[k] += h[k]
+    rc = 0
+    for kname, header, scratch in bad:
+        sys.stderr.write("loop check: %s loop %s has %d scratch accesses beside its %s\n" % (kname, header, scratch, "hot instructions"))
+        rc = 1
+    for k in rules:
+        if not seen[k]:
+            sys.stderr.write("loop check: no function matching '%s' in %s -- the gate would be off\n" % (k, " ".join(files)))
+            rc = 1
+        elif not hot[k]:
+            sys.stderr.write("loop check: functions matching '%s' have no loop with %s -- the gate would be off\n" % (k, rules[k]))
+            rc = 1
+    return rc
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

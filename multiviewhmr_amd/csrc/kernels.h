@@ -35,6 +35,9 @@ unsigned long long dynamic_lds_cache_key(int device, const void *kernel);
 // (fp32 channels-last accumulator -> feature dtype, planar).
 hipError_t launch_to_channels_last(const void *src, void *dst, const Problem &p, hipStream_t s);
 hipError_t launch_grad_to_planar(const float *srcT, void *dst, const Problem &p, hipStream_t s);
+// column-major quad-planar fp32 copy (MVHMR_LAYOUT_QUAD) -> channels-last in the feature dtype (gated like the gather kernels)
+bool quad_to_channels_last_supported(const Problem &p);
+hipError_t launch_quad_to_channels_last(const void *srcK, void *dst, const Problem &p, hipStream_t s);
 // channels-last fp32 accumulator -> channels-last feature dtype (C4 == C required)
 hipError_t launch_grad_cast(const float *srcT, void *dst, const Problem &p, hipStream_t s);
 
@@ -83,8 +86,8 @@ hipError_t launch_conv1x1_wgrad(const float *gy, const float *x, float *dW, floa
 hipError_t launch_conv1x1_planar(const float *x, const float *w, const float *bias, float *dst, int BV, int Cin, int Cout, int HW, hipStream_t s);
 hipError_t launch_conv1x1_quad(const float *x, const float *w, const float *bias, void *dst, int BV, int Cin, int Cout, int H, int W,
                                hipStream_t s);
-// column-major quad-planar -> row-major quad-planar (planes = B * V * C / 4)
-hipError_t launch_quad_transpose(const void *src, void *dst, int planes, int H, int W, hipStream_t s);
+// column-major quad-planar -> row-major quad-planar (planes = B * V * C / 4); gated like the brick kernels
+hipError_t launch_quad_transpose(const void *src, void *dst, int planes, int H, int W, const Gate &gate, hipStream_t s);
 
 hipError_t launch_build_coords(float *coords_out, const float *rot, const float *center, int B, int S,
                                const double pos[3], const double sides[3], hipStream_t s);

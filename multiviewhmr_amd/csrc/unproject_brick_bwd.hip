@@ -2,7 +2,7 @@
 //
 // The gather backward scatters every tap with a global float atomic: 4 taps x 4 B per (voxel, view, channel) = 137 GB of
 // atomic traffic at the north-star size against a chip-wide rate of ~1.3 TB/s -- ~0.1 s.  Here the same bricks and
-// windows as the forward (unproject_brick.hip) are used to sum on chip first:
+// windows as the forward (brick_fwd_kernel.h) are used to sum on chip first:
 //   per brick and channel quad   re-sample the brick's voxels from the LDS-staged feature window (recompute, nothing
 //                                is saved by the forward), apply the aggregate's Jacobian (aggregate_grad), and add
 //                                ds * w into a GRADIENT window in LDS (planar per channel, so that a wave's lanes --

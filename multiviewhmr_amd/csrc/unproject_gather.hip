@@ -10,7 +10,7 @@
 //   phase 3 = the (voxel x channel) tile is turned through LDS so every store writes 128-B runs of
 //             consecutive voxels of one channel of the (B,C,X,Y,Z) output
 // Feature reads come from L2 / Infinity Cache (each (b,v) map is re-read by many blocks), the output is
-// written exactly once.  The brick variant (unproject_brick.hip) replaces the L2 gather by LDS patches.
+// written exactly once.  The brick variant (brick_fwd_kernel.h, unproject_brick_bwd.hip) replaces the L2 gather by LDS patches.
 #include "device_common.h"
 #include "kernels.h"
 
@@ -305,6 +305,35 @@ k_to_channels_last(const T *__restrict__ src, T *__restrict__ dst, int C, int C4
     }
 }
 
+// column-major quad-planar fp32 (BV, C/4, W, H, 4) -> channels-last (BV, HW, C) in the feature dtype: what the gather kernels read when
+// the caller handed over MVHMR_LAYOUT_QUAD (the fused 1x1 conv's output) and the geometry gate selects them.  One block = one image
+// column x, a band of 2^band_log2 rows, every channel quad: (16 << band_log2)-B runs read along y per quad, one C * sizeof(T) run
+// written per pixel.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_quad_to_channels_last(const float4 *__restrict__ src, T *__restrict__ dst, int C, int H, int W, int band_log2, Gate gate)
+{
+    if (gated_off(gate)) return;
+    extern __shared__ float4 qtile[];                                            // [row][quad], quad count padded to odd
+    const int nq = C >> 2, ldq = nq | 1, band = 1 << band_log2;
+    const long long bv = blockIdx.y;
+    const int bands = (H + band - 1) >> band_log2;
+    const int x = blockIdx.x / bands, y0 = (blockIdx.x % bands) << band_log2;
+    const int rows = H - y0 < band ? H - y0 : band;
+    const long long HW = (long long)H * W;
+    const float4 *sp = src + bv * nq * HW + (long long)x * H + y0;
+    for (int i = threadIdx.x; i < band * nq; i += 256) {
+        const int q = i >> band_log2, r = i & (band - 1);
+        if (r < rows) qtile[r * ldq + q] = sp[(long long)q * HW + r];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < rows * nq; i += 256) {
+        const int r = i / nq, q = i - r * nq;
+        const float4 v = qtile[r * ldq + q];
+        Vec4<T>::store(dst + ((bv * HW + (long long)(y0 + r) * W + x) * C + 4 * q), f32x4{{v.x, v.y, v.z, v.w}});
+    }
+}
+
 // fp32 channels-last gradient accumulator (BV, HW, C4) -> (BV, C, HW) in the feature dtype
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -453,6 +482,30 @@ hipError_t launch_to_channels_last(const void *src, void *dst, const Problem &p,
     const dim3 grid((HW + 63) / 64, (p.C4 + 63) / 64, (unsigned)(p.B * p.V));
     if (p.feat_f16) hipLaunchKernelGGL(k_to_channels_last<__half>, grid, dim3(256), 0, s, (const __half *)src, (__half *)dst, p.C, p.C4, HW, make_gate(p, false));
     else hipLaunchKernelGGL(k_to_channels_last<float>, grid, dim3(256), 0, s, (const float *)src, (float *)dst, p.C, p.C4, HW, make_gate(p, false));
+    return hipGetLastError();
+}
+
+// rows per block: the largest power of two (<= 32) whose tile of all channel quads fits 64 KiB of LDS; -1: not even 4 rows (C > 4092)
+static int quad_band_log2(const Problem &p)
+{
+    for (int b = 5; b >= 2; --b)
+        if (((size_t)((p.C / 4) | 1) * sizeof(float4) << b) <= 64 * 1024) return b;
+    return -1;
+}
+
+bool quad_to_channels_last_supported(const Problem &p)
+{
+    return p.C % 4 == 0 && quad_band_log2(p) >= 0 && (long long)p.B * p.V <= 65535;
+}
+
+hipError_t launch_quad_to_channels_last(const void *srcK, void *dst, const Problem &p, hipStream_t s)
+{
+    if (!quad_to_channels_last_supported(p)) return hipErrorNotSupported;
+    const int b = quad_band_log2(p);
+    const size_t lds = (size_t)((p.C / 4) | 1) * sizeof(float4) << b;
+    const dim3 grid((unsigned)(p.W * ((p.H + (1 << b) - 1) >> b)), (unsigned)(p.B * p.V));
+    if (p.feat_f16) hipLaunchKernelGGL(k_quad_to_channels_last<__half>, grid, dim3(256), lds, s, (const float4 *)srcK, (__half *)dst, p.C, p.H, p.W, b, make_gate(p, false));
+    else hipLaunchKernelGGL(k_quad_to_channels_last<float>, grid, dim3(256), lds, s, (const float4 *)srcK, (float *)dst, p.C, p.H, p.W, b, make_gate(p, false));
     return hipGetLastError();
 }
 

@@ -1,5 +1,6 @@
 """The two build gates of csrc/Makefile (no GPU needed): check_resources.py rejects scratch in the kernels that wait on hand-counted
-vmcnt, check_loops.py rejects scratch inside the tap-reading loops of k_fwd_brick_groups."""
+vmcnt, check_loops.py rejects scratch inside the tap-reading loops of k_fwd_brick_groups and the accumulation loop of k_bwd_brick,
+and refuses to pass vacuously."""
 import os
 import subprocess
 import sys
@@ -8,8 +9,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "multiviewhmr_amd", "csrc")
 
 
-def _run(script, path):
-    return subprocess.run([sys.executable, os.path.join(CSRC, script), path], capture_output=True, text=True)
+def _run(script, path, rules=("k_fwd_brick_groups:ds_read_b128",)):
+    args = [path] if script == "check_resources.py" else list(rules) + ["--", path]
+    return subprocess.run([sys.executable, os.path.join(CSRC, script)] + args, capture_output=True, text=True)
 
 
 def test_check_resources_flags_scratch_in_the_counted_kernels(tmp_path):
@@ -17,7 +19,7 @@ def test_check_resources_flags_scratch_in_the_counted_kernels(tmp_path):
     ok = tmp_path / "ok.txt"
     ok.write_text(remark % ("_ZN5mvhmr11k_fwd_brickILi0ELi4ELi1024EfLi2EEEv", 0) + remark % ("_ZN5mvhmr11k_bwd_brickILi0ELi4ELi1024EfLi16EEEv", 452)
                   + remark % ("_ZN5mvhmr18k_fwd_brick_groupsILi0ELi8EfEEv", 372))
-    assert _run("check_resources.py", str(ok)).returncode == 0            # backward: vmcnt(0) only; groups: checked on the asm instead
+    assert _run("check_resources.py", str(ok)).returncode == 0            # backward and groups: their loops are checked on the asm instead
     bad = tmp_path / "bad.txt"
     bad.write_text(remark % ("_ZN5mvhmr11k_fwd_brickILi0ELi4ELi1024EfLi2EEEv", 80))
     r = _run("check_resources.py", str(bad))
@@ -37,4 +39,37 @@ def test_check_loops_flags_scratch_next_to_the_tap_reads(tmp_path):
     bad = tmp_path / "bad.s"
     bad.write_text(head + cold + loop_ok + loop_bad + tail)
     r = _run("check_loops.py", str(bad))
-    assert r.returncode == 1 and ".LBB3_244" in r.stderr
+    assert r.returncode == 1 and "BB3_232" in r.stderr                      # a spill in ANY block of the loop that holds the tap reads
+    # the spill sits in a latch block WITHOUT tap reads of the same loop: still that loop
+    latch = ".LBB3_245:                              ;   in Loop: Header=BB3_232 Depth=1\n\tscratch_load_dword v7, off, off offset:40\n\ts_cbranch_scc0 .LBB3_232\n"
+    split = tmp_path / "split.s"
+    split.write_text(head + cold + loop_ok + latch + tail)
+    assert _run("check_loops.py", str(split)).returncode == 1
+    # a fall-through block (no label) inside the loop
+    ft = "; %bb.246:                              ;   in Loop: Header=BB3_232 Depth=1\n\tscratch_store_dword off, v7, off\n"
+    fall = tmp_path / "fall.s"
+    fall.write_text(head + cold + loop_ok + ft + tail)
+    assert _run("check_loops.py", str(fall)).returncode == 1
+
+
+def test_check_loops_does_not_pass_vacuously(tmp_path):
+    renamed = tmp_path / "renamed.s"
+    renamed.write_text("_ZN5mvhmr9k_renamedILi0EEEvPK:\n.LBB0_1:                              ;   in Loop: Header=BB0_1 Depth=1\n\tds_read_b128 v[0:3], v9\n.Lfunc_end0:\n")
+    r = _run("check_loops.py", str(renamed))
+    assert r.returncode == 1 and "no function matching" in r.stderr
+    no_loop = tmp_path / "noloop.s"
+    no_loop.write_text("_ZN5mvhmr18k_fwd_brick_groupsILi0ELi8EfEEvPK:\n.LBB0_1:\n\tv_mul_f32_e32 v0, v0, v7\n.Lfunc_end0:\n")
+    r = _run("check_loops.py", str(no_loop))
+    assert r.returncode == 1 and "no loop with" in r.stderr
+
+
+def test_check_loops_covers_the_backward_accumulation_loop(tmp_path):
+    head = "_ZN5mvhmr11k_bwd_brickILi0ELi4ELi1024EfLi16EEEvPK:\n"
+    loop = ".LBB7_10:                              ;   in Loop: Header=BB7_10 Depth=1\n\tds_add_u32 v3, v4\n"
+    spill = ".LBB7_11:                              ;   in Loop: Header=BB7_10 Depth=1\n\tscratch_store_dword off, v7, off\n"
+    ok, bad = tmp_path / "ok.s", tmp_path / "bad.s"
+    ok.write_text(head + loop + ".Lfunc_end7:\n")
+    bad.write_text(head + loop + spill + ".Lfunc_end7:\n")
+    rules = ("k_bwd_brick:ds_add_u32",)
+    assert _run("check_loops.py", str(ok), rules).returncode == 0
+    assert _run("check_loops.py", str(bad), rules).returncode == 1

@@ -159,7 +159,8 @@ def test_brick_variant_vs_oracle(shape, mode, gpu):
                _err(out.cpu().numpy(), ref), TOL)
     assert torch.equal(out, aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick"))   # deterministic
     gat = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="gather")
-    assert float((out - gat).abs().max()) <= 2e-6         # same arithmetic, two kernels
+    record_err("brick vs gather fwd %s V%d C%d %dx%d vol%s" % (mode, shape["V"], shape["C"], shape["H"], shape["W"], shape["vol"]),
+               float((out - gat).abs().max()), 2e-6)         # same arithmetic, two kernels
 
 
 @pytest.mark.parametrize("shape", [
@@ -296,7 +297,7 @@ def test_brick_backward_keeps_per_channel_precision(gpu):
     for ch in range(8):
         ref_c, got_c = gref[:, :, ch], got[:, :, ch]
         scale = float(np.abs(ref_c).max())
-        assert float(np.abs(got_c - ref_c).max()) <= 2e-5 * scale, (ch, scale)
+        record_err("brick bwd per-channel precision, channel %d (scale %.1e)" % (ch, scale), _err(got_c, ref_c), 2e-5 * scale)
     assert not got[:, :, 3].any()
 
 
@@ -311,7 +312,7 @@ def test_brick_variant_with_cameras_inside_the_volume(gpu):
     for mode in MODES:
         out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick")
         ref = cport.forward(feats, d["proj"], coords, mode)
-        assert float(np.abs(out.cpu().numpy() - ref).max()) <= TOL
+        record_err("brick fwd, cameras inside the volume (%s)" % mode, _err(out.cpu().numpy(), ref), TOL)
 
 
 def test_channels_last_features_skip_the_layout_pass(gpu):
@@ -329,7 +330,7 @@ def test_channels_last_features_skip_the_layout_pass(gpu):
     pl = planar.detach().requires_grad_(True)
     aggregation.unprojection(pl, p, c).backward(go)
     assert cl.grad.shape == cl.shape
-    assert float((cl.grad - pl.grad).abs().max()) <= 1e-5
+    record_err("channels-last vs planar features, bwd", float((cl.grad - pl.grad).abs().max()), 1e-5)
 
 
 @pytest.mark.parametrize("views", (4, 8))
@@ -343,23 +344,26 @@ def test_fp16_storage_mode(views, gpu):
     out16 = aggregation.unprojection(f16, p, c)
     assert out16.dtype == torch.float16
     bound = TOL + np.abs(ref).max() * 2.0 ** -11
-    assert float(np.abs(out16.float().cpu().numpy() - ref).max()) <= bound
-    for variant in ("brick", "gather"):         # both kernel families serve fp16 storage (brick: fp32 staging, fp16 stores)
+    record_err("fp16 storage fwd auto V%d" % views, _err(out16.float().cpu().numpy(), ref), bound)
+    for variant in ("brick", "gather"):         # both kernel families serve fp16 storage (brick: fp16 or fp32 staging, fp16 stores)
         o = aggregation.unprojection(f16, p, c, variant=variant)
-        assert o.dtype == torch.float16 and float(np.abs(o.float().cpu().numpy() - ref).max()) <= bound
+        assert o.dtype == torch.float16
+        record_err("fp16 storage fwd %s V%d" % (variant, views), _err(o.float().cpu().numpy(), ref), bound)
         fg = f16.clone().requires_grad_(True)
         gg = torch.ones_like(o)
         aggregation.unprojection(fg, p, c, variant=variant).backward(gg)
         gr = cport.backward(gg.float().cpu().numpy(), f16.float().cpu().numpy(), proj, coords, "softmax")
-        assert float(np.abs(fg.grad.float().cpu().numpy() - gr).max()) <= TOL + np.abs(gr).max() * 2.0 ** -10
+        record_err("fp16 storage bwd %s V%d" % (variant, views), _err(fg.grad.float().cpu().numpy(), gr), TOL + np.abs(gr).max() * 2.0 ** -10)
     out32 = aggregation.unprojection(f16, p, c, out_dtype=torch.float32)
-    assert out32.dtype == torch.float32 and float(np.abs(out32.cpu().numpy() - ref).max()) <= TOL
+    assert out32.dtype == torch.float32
+    record_err("fp16 features, fp32 volume V%d" % views, _err(out32.cpu().numpy(), ref), TOL)
     f16g = f16.clone().requires_grad_(True)
     go = torch.randn_like(out16)
     aggregation.unprojection(f16g, p, c).backward(go)
     gref = cport.backward(go.float().cpu().numpy(), f16.float().cpu().numpy(), proj, coords, "softmax")
     gb = TOL + np.abs(gref).max() * 2.0 ** -10
-    assert f16g.grad.dtype == torch.float16 and float(np.abs(f16g.grad.float().cpu().numpy() - gref).max()) <= gb
+    assert f16g.grad.dtype == torch.float16
+    record_err("fp16 storage bwd auto, random grad_out V%d" % views, _err(f16g.grad.float().cpu().numpy(), gref), gb)
 
 
 # ------------------------------------------------------------------------------------ size-independent properties at BASELINE config[1]
@@ -378,17 +382,17 @@ def test_config1_properties(config1):
     mean = aggregation.unprojection(f, p, c, aggregation_method="mean")
     mx = aggregation.unprojection(f, p, c, aggregation_method="max")
     sm = aggregation.unprojection(f, p, c, aggregation_method="softmax")
-    assert float((mean - s / V).abs().max()) <= 1e-6
+    record_err("configs[1] mean == sum / V", float((mean - s / V).abs().max()), 1e-6)
     assert bool((mx >= mean - 1e-6).all()) and bool((sm <= mx + 1e-5).all()) and bool((sm >= mean - 1e-5).all())
     # 'sum' is linear in the features
     g = torch.randn_like(f)
     s2 = aggregation.unprojection(2.0 * f + g, p, c, aggregation_method="sum")
     sg = aggregation.unprojection(g, p, c, aggregation_method="sum")
-    assert float((s2 - (2.0 * s + sg)).abs().max()) <= 2e-5
+    record_err("configs[1] linearity of sum", float((s2 - (2.0 * s + sg)).abs().max()), 2e-5)
     # the aggregate does not care about the order of the views
     perm = torch.tensor([2, 0, 3, 1], device=f.device)
     smp = aggregation.unprojection(f[:, perm].contiguous(), p[:, perm].contiguous(), c, aggregation_method="softmax")
-    assert float((smp - sm).abs().max()) <= 2e-6
+    record_err("configs[1] view permutation", float((smp - sm).abs().max()), 2e-6)
     # samples are independent: a batch shard equals the same rows of the full batch (what multi-GPU sharding relies on)
     half = aggregation.unprojection(f[4:].contiguous(), p[4:].contiguous(), c[4:].contiguous())
     assert torch.equal(half, sm[4:])
@@ -404,7 +408,7 @@ def test_config1_sample_vs_oracle(config1):
     f, p, c = config1
     out = aggregation.unprojection(f, p, c)
     ref = cport.forward(f[5:6].cpu().numpy(), p[5:6].cpu().numpy(), c[5:6].cpu().numpy(), "softmax")
-    assert float(np.abs(out[5:6].cpu().numpy() - ref).max()) <= TOL
+    record_err("configs[1] fwd (sample 5, all channels)", _err(out[5:6].cpu().numpy(), ref), TOL)
 
 
 # ------------------------------------------------------------------------------------ VolumeGenerator end to end
@@ -473,7 +477,7 @@ def test_raw_c_abi_call(gpu):
                                    vp(ws.data_ptr()), ctypes.c_size_t(need), vp(torch.cuda.current_stream().cuda_stream))
     assert rc == 0
     torch.cuda.synchronize()
-    assert float(np.abs(out.cpu().numpy() - d["out_softmax"]).max()) <= TOL
+    record_err("raw C-ABI call vs reference golden", _err(out.cpu().numpy(), d["out_softmax"]), TOL)
 
 
 def test_wrong_device_and_dtype_raise(gpu):
@@ -507,7 +511,7 @@ def test_config2_fp16_forward_backward_full_size(gpu):
     assert out.dtype == torch.float16 and tuple(out.shape) == (B, C, S, S, S)
     chans = [0, 1, 127, 255]
     err, ref = _oracle_on_channels(f.detach(), p, c, out.detach(), chans, b=31)
-    assert err <= TOL + np.abs(ref).max() * 2.0 ** -11
+    record_err("configs[2] fp16 fwd (sample 31, 4 channels)", err, TOL + np.abs(ref).max() * 2.0 ** -11)
     # backward: gradient of sum(out * g) for a sparse g touches every code path; check it on a channel slice
     g = torch.zeros_like(out)
     g[31, chans] = torch.randn(len(chans), S, S, S, device=gpu, dtype=torch.float16)
@@ -516,7 +520,7 @@ def test_config2_fp16_forward_backward_full_size(gpu):
     gref = cport.backward(g[31:32, chans].float().cpu().numpy(), f[31:32, :, chans].detach().float().cpu().numpy(),
                           proj, coords, "softmax")
     got = f.grad[31:32, :, chans].float().cpu().numpy()
-    assert float(np.abs(got - gref).max()) <= TOL + np.abs(gref).max() * 2.0 ** -10
+    record_err("configs[2] fp16 bwd (sample 31, 4 channels)", _err(got, gref), TOL + np.abs(gref).max() * 2.0 ** -10)
     assert float(f.grad[:31].abs().max()) == 0.0 and float(f.grad[31, :, 2:127].abs().max()) == 0.0   # nothing leaks across samples / channels
     del out, g, f
     torch.cuda.empty_cache()
@@ -540,7 +544,7 @@ def test_config3_eight_views_per_gpu_shard(gpu):
                                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == _capi.VARIANT["brick"]
     mean = aggregation.unprojection(f, p, c, aggregation_method="mean")
     s = aggregation.unprojection(f, p, c, aggregation_method="sum")
-    assert float((mean - s / V).abs().max()) <= 1e-6
+    record_err("configs[3] mean == sum / V", float((mean - s / V).abs().max()), 1e-6)
     # a rank's shard equals the same rows of the whole batch (what the 4-GPU run relies on)
     part = aggregation.unprojection(f[4:8].contiguous(), p[4:8].contiguous(), c[4:8].contiguous())
     assert torch.equal(part, out[4:8])
@@ -560,12 +564,12 @@ def test_config4_large_volume_64bit_indexing(gpu):
     out = aggregation.unprojection(f, p, c)                    # brick variant
     assert out.numel() * 4 >= 2 ** 33 and out[0].numel() * 4 >= 2 ** 32
     err, _ = _oracle_on_channels(f, p, c, out, [0, 511], b=1)
-    assert err <= TOL
+    record_err("configs[4] geometry B=2 fwd (sample 1, 2 channels)", err, TOL)
     gat = aggregation.unprojection(f, p, c, variant="gather")
     worst = 0.0
     for ch in (0, 255, 256, 511):                              # compare kernels plane by plane (keeps temporaries small)
         worst = max(worst, float((out[:, ch] - gat[:, ch]).abs().max()))
-    assert worst <= 2e-6
+    record_err("configs[4] geometry B=2, brick vs gather (4 channel planes)", worst, 2e-6)
     del out, gat
     torch.cuda.empty_cache()
 
@@ -598,7 +602,7 @@ def test_forward_is_graph_capturable(gpu):
     g.replay()
     torch.cuda.synchronize()
     ref = cport.forward(f.cpu().numpy(), proj, coords, "softmax")
-    assert float(np.abs(out.cpu().numpy() - ref).max()) <= TOL
+    record_err("HIP-graph replay fwd", _err(out.cpu().numpy(), ref), TOL)
 
 
 # ------------------------------------------------------------------------------------ round 2: shard-size forward AND backward
@@ -714,7 +718,7 @@ def test_non_finite_grad_out_stays_visible_in_both_backward_variants(bad, gpu):
     # everything outside the poisoned (sample, channel) agrees between the two kernels
     a, b = grads["brick"].clone(), grads["gather"].clone()
     a[1, :, 5] = 0; b[1, :, 5] = 0
-    assert float((a - b).abs().max()) <= TOL
+    record_err("non-finite grad_out (%s): brick vs gather outside the poisoned channel" % bad, float((a - b).abs().max()), TOL)
     # the gather variant poisons exactly the reference's pixels (float scatter); the brick variant a superset of them
     bad_g, bad_b = ~torch.isfinite(grads["gather"]), ~torch.isfinite(grads["brick"])
     assert bool((bad_b | ~bad_g).all())
@@ -818,6 +822,12 @@ def test_packed_cameras_give_the_same_volume_without_the_camera_loop(gpu):
         b = gen(_dev(d, "features_in", gpu), _dev(d, "proj_org", gpu), packed)
     assert torch.equal(a, b)
     record_err("volgen volume train_mpii (packed cameras)", _err(b.cpu().numpy(), d["volume"]), TOL)
+    # a loader may pack the cameras on the HOST: the projections must reach the kernels as device memory
+    packed["cameras_packed"] = aggregation.pack_cameras(batch["cameras"], "cpu")
+    np.random.seed(seed)
+    with torch.no_grad():
+        c = gen(_dev(d, "features_in", gpu), _dev(d, "proj_org", gpu), packed)
+    assert torch.equal(a, c)
 
 
 # ------------------------------------------------------------------------------------ 1x1 conv fused with the layout pass
@@ -894,7 +904,7 @@ def test_conv1x1_wgrad_matches_einsum(gpu):
 
 
 @pytest.mark.parametrize("training", (False, True))
-def test_volume_generator_fused_path_equals_the_unfused_one(training, gpu):
+def test_volume_generator_fused_path_equals_the_unfused_one(training, gpu, monkeypatch):
     """VolumeGenerator with the fused conv (default where the brick kernels run) against the same module with fused_conv off:
     volume, and in training the gradients of the input features, the conv weight and its bias"""
     B, V, C, H, S, IMG = 2, 4, 128, 32, 32, 128
@@ -918,6 +928,9 @@ def test_volume_generator_fused_path_equals_the_unfused_one(training, gpu):
     gen = aggregation.VolumeGenerator(volume_size=S, input_channels=C, output_channels=C, device=gpu).train(training)
     x = torch.randn(B, V, C, H, H, device=gpu)
     outs, grads = {}, {}
+    fused_calls = []
+    real_apply = aggregation._FusedAggregate.apply
+    monkeypatch.setattr(aggregation._FusedAggregate, "apply", lambda *a: (fused_calls.append(1), real_apply(*a))[1])
     for fused in (True, False):
         gen.fused_conv = fused
         gen.zero_grad(set_to_none=True)
@@ -930,9 +943,109 @@ def test_volume_generator_fused_path_equals_the_unfused_one(training, gpu):
             go = torch.randn(vol.shape, device=gpu, generator=torch.Generator(device=gpu).manual_seed(5))
             vol.backward(go)
             grads[fused] = (xi.grad.clone(), gen.process_feature[0].weight.grad.clone(), gen.process_feature[0].bias.grad.clone())
-    assert gen._fused_cache and all(gen._fused_cache.values())                      # the fused path really ran
+    assert len(fused_calls) == 1                                                    # the fused path really ran, and only when switched on
     scale = float(outs[False].abs().max())
     record_err("fused vs unfused volume (training=%s)" % training, float((outs[True] - outs[False]).abs().max()), 2e-5 * scale + 1e-6)
     if training:
+        # two fp32 summation orders of up to B*V*Hf*Wf terms: a few dozen ulps of the largest gradient (observed: ~5)
         for name, a, b in zip(("input", "weight", "bias"), grads[True], grads[False]):
-            record_err("fused vs unfused grad %s" % name, float((a - b).abs().max()), 1e-4 * max(1.0, float(b.abs().max())))
+            record_err("fused vs unfused grad %s" % name, float((a - b).abs().max()), 32 * 2.0 ** -23 * float(b.abs().max()) + 1e-6)
+
+
+def _rig(B, V, radius, img, seed):
+    rng = np.random.default_rng(seed)
+    cams = [[None] * B for _ in range(V)]
+    for v in range(V):
+        az = 2 * np.pi * v / V + 0.3
+        for b in range(B):
+            eye = np.array([np.cos(az), np.sin(az), 0.0]) * radius * rng.uniform(0.95, 1.05) + np.array([0, 0, 0.3 * radius])
+            fwd = -eye / np.linalg.norm(eye)
+            right = np.cross(fwd, [0, 0, 1.0]); right /= np.linalg.norm(right)
+            R = np.stack([right, np.cross(fwd, right), fwd])
+            cam = multiview.Camera(R, -R @ eye, [[1145.0, 0, 512], [0, 1145.0, 512], [0, 0, 1]])
+            cam.update_after_crop((150, 150, 850, 850))
+            cam.update_after_resize((700, 700), (img, img))
+            cams[v][b] = cam
+    return cams
+
+
+def test_fused_route_follows_the_gate_when_the_rig_changes_between_calls(gpu):
+    """Same module, same shapes, two camera rigs: the fused route decides brick / gather on the device per call.
+    Each call's volume is bit-equal to the explicit variant the gate's own (synchronous) query names for that rig, run on the same
+    quad-planar conv output -- and the two rigs really get different answers."""
+    B, V, C, H, S, IMG = 2, 4, 128, 96, 32, 384
+    L = _capi.lib()
+    vp = ctypes.c_void_p
+    torch.manual_seed(3)
+    gen = aggregation.VolumeGenerator(volume_size=S, input_channels=C, output_channels=C, cuboid_side=1250.0, device=gpu).eval()
+    conv = gen.process_feature[0]
+    x = torch.randn(B, V, C, H, H, device=gpu)
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    answers = []
+    for radius in (5000.0, 1400.0, 5000.0):                                         # far rig, near rig, far rig again
+        cams = _rig(B, V, radius, IMG, seed=int(radius))
+        batch = dict(images=np.zeros((B, V, IMG, IMG, 3), np.uint8), cameras=cams,
+                     keypoints_3d=[np.zeros((17, 3), np.float32) for _ in range(B)])
+        proj_org = torch.from_numpy(np.stack([[cams[v][b].projection for v in range(V)] for b in range(B)]).astype(np.float32)).to(gpu)
+        with torch.no_grad():
+            vol = gen(x, proj_org, batch)
+        # the same pieces by hand: conv -> quad copy, the gate's answer for this rig, the explicit variants on that copy
+        proj = torch.from_numpy(aggregation.feature_level_projections(cams, (IMG, IMG), (H, H))).to(gpu)
+        rots, centers = gen.volume_pose(batch, proj_org, (IMG, IMG))
+        rots, centers = rots.to(gpu).contiguous(), centers.to(gpu).contiguous()
+        cub = gen.cuboid()
+        pos = (ctypes.c_double * 3)(*[float(v) for v in cub.position])
+        sid = (ctypes.c_double * 3)(*[float(v) for v in cub.sides])
+        quad = torch.empty(B * V * C * H * H, device=gpu)
+        _capi.check(L.mvhmr_conv1x1_to_quad(vp(x.data_ptr()), vp(conv.weight.data_ptr()), vp(conv.bias.data_ptr()), vp(quad.data_ptr()),
+                                            B * V, C, C, H, H, stream))
+        meta = torch.empty((B, V, C, H, H), dtype=torch.float32, device="meta")
+        dq = aggregation._make_desc(meta, (S, S, S), _capi.AGG["softmax"], torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["auto"])
+        got = L.mvhmr_unproject_query_variant_cuboid(ctypes.byref(dq), vp(proj.data_ptr()), vp(rots.data_ptr()), vp(centers.data_ptr()), pos, sid, stream)
+        assert got in (_capi.VARIANT["brick"], _capi.VARIANT["gather"])
+        answers.append(got)
+        outs = {}
+        for name in ("brick", "gather"):
+            d = aggregation._make_desc(meta, (S, S, S), _capi.AGG["softmax"], torch.float32, _capi.LAYOUT_QUAD, _capi.VARIANT[name])
+            o = torch.empty(B, C, S, S, S, device=gpu)
+            nb = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(d))
+            ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=gpu)
+            _capi.check(L.mvhmr_unproject_forward_cuboid(ctypes.byref(d), vp(quad.data_ptr()), vp(proj.data_ptr()), vp(rots.data_ptr()),
+                                                         vp(centers.data_ptr()), pos, sid, vp(o.data_ptr()), vp(ws.data_ptr()), nb, stream))
+            outs[name] = o
+        chosen = "brick" if got == _capi.VARIANT["brick"] else "gather"
+        other = "gather" if chosen == "brick" else "brick"
+        assert torch.equal(vol, outs[chosen]), (radius, chosen)
+        assert not torch.equal(vol, outs[other]) or torch.equal(outs["brick"], outs["gather"])
+        record_err("fused route, rig radius %d: %s vs the other variant" % (radius, chosen), float((outs["brick"] - outs["gather"]).abs().max()), 2e-5)
+    assert answers == [_capi.VARIANT["brick"], _capi.VARIANT["gather"], _capi.VARIANT["brick"]], answers
+
+
+def test_quad_planar_features_through_the_gate_backward(gpu):
+    """MVHMR_LAYOUT_QUAD + AUTO in the backward: the gradient (planar) equals the one from planar features for both gate answers"""
+    L = _capi.lib()
+    vp = ctypes.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    for shape, expect in ((dict(B=1, V=4, C=8, H=320, W=320, vol=(8, 8, 32)), "gather"), (dict(B=2, V=4, C=8, H=24, W=24, vol=(8, 8, 32)), "brick")):
+        feats, proj, coords = _ring_problem(seed=5, **shape)
+        f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+        p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+        out = aggregation.unprojection(f, p, c)
+        go = torch.from_numpy(np.random.default_rng(9).standard_normal(tuple(out.shape), dtype=np.float32)).to(gpu)
+        out.backward(go)
+        d = aggregation._make_desc(f, c, _capi.AGG["softmax"], torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["auto"])
+        quad = torch.empty(L.mvhmr_feature_layout_bytes(ctypes.byref(d), _capi.LAYOUT_QUAD), dtype=torch.uint8, device=gpu)
+        _capi.check(L.mvhmr_convert_features(ctypes.byref(d), vp(f.data_ptr()), _capi.LAYOUT_QUAD, vp(quad.data_ptr()), stream))
+        d.feat_layout = _capi.LAYOUT_QUAD
+        assert L.mvhmr_unproject_backward_supported(ctypes.byref(d)) == 1
+        o2 = torch.empty_like(out)
+        nb = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=gpu)
+        _capi.check(L.mvhmr_unproject_forward(ctypes.byref(d), vp(quad.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(o2.data_ptr()), vp(ws.data_ptr()), nb, stream))
+        assert torch.equal(o2, out.detach()), expect
+        g2 = torch.empty_like(f)
+        nb = L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=gpu)
+        _capi.check(L.mvhmr_unproject_backward(ctypes.byref(d), vp(go.data_ptr()), vp(quad.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(g2.data_ptr()),
+                                               vp(ws.data_ptr()), nb, stream))
+        record_err("quad-planar features through the gate, bwd (%s)" % expect, float((g2 - f.grad).abs().max()), _bound(f.grad.cpu().numpy()))
