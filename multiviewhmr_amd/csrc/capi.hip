@@ -120,6 +120,20 @@ bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
     return (d->feat_layout == MVHMR_LAYOUT_BVCHW || d->feat_layout == MVHMR_LAYOUT_QUAD) && d->variant != MVHMR_VARIANT_GATHER && brick_bwd_supported(p);
 }
 
+// The gather family's backward for planar / quad-planar features: the plane kernel (no global atomics) where the maps fit LDS, else
+// the per-tap scatter.  Channels-last features keep the scatter (its accumulator is the caller's own tensor).
+bool bwd_uses_plane(const mvhmr_unproject_desc *d, const Problem &p)
+{
+    return d->feat_layout != MVHMR_LAYOUT_BVHWC && plane_bwd_supported(p);
+}
+// bytes between the converted feature copy and the gate counter of a gated backward: the brick side's accumulator or the plane
+// side's tap table, whichever is larger
+size_t bwd_mid_bytes(const mvhmr_unproject_desc *d, const Problem &p)
+{
+    const size_t a = gradT_bytes(p), b = bwd_uses_plane(d, p) ? align_up(plane_table_bytes(p)) : 0;
+    return a > b ? a : b;
+}
+
 // AUTO on planar input, for a shape both variants serve: the variant is chosen on the device from the geometry (gate.h).
 // Quad-planar input is gated the same way (the gather side then converts it to channels-last first), so a caller that keeps
 // only the fused conv's copy never pins a variant the geometry does not suit.
@@ -267,8 +281,9 @@ size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
-    if (geometry_gated_bwd(desc, p) && bwd_uses_brick(desc, p)) return conv_bytes(p) + gradT_bytes(p) + kGateBytes;
+    if (geometry_gated_bwd(desc, p) && bwd_uses_brick(desc, p)) return conv_bytes(p) + bwd_mid_bytes(desc, p) + kGateBytes;
     if (bwd_uses_brick(desc, p)) return brick_workspace_bytes(p) + gradT_bytes(p);
+    if (bwd_uses_plane(desc, p)) return (desc->feat_layout == MVHMR_LAYOUT_BVCHW ? brick_workspace_bytes(p) : 0) + align_up(plane_table_bytes(p));
     size_t need = desc->feat_layout != MVHMR_LAYOUT_BVHWC ? featT_bytes(p) : 0;
     if (!grad_in_place(desc, p)) need += gradT_bytes(p);
     return need;
@@ -363,9 +378,27 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
         return fail(MVHMR_ERR_UNSUPPORTED, "the brick variant does not support this shape / dtype / layout");
     if (geometry_gated_bwd(desc, p) && bwd_uses_brick(desc, p)) {
         float *acc = reinterpret_cast<float *>(ws + conv_bytes(p));               // quad-planar or channels-last accumulator
-        rc = arm_gate(p, ws + conv_bytes(p) + gradT_bytes(p), proj, coords, brick_bwd_gate_geom(p), s);
+        rc = arm_gate(p, ws + conv_bytes(p) + bwd_mid_bytes(desc, p), proj, coords, brick_bwd_gate_geom(p), s);
         if (rc != MVHMR_OK) return rc;
         const bool quad = desc->feat_layout == MVHMR_LAYOUT_QUAD;
+        if (bwd_uses_plane(desc, p)) {
+            // brick side: row-major quad copy, LDS windows, float-atomic flush into `acc`, layout pass; gather side: the plane kernel on
+            // the column-major quad copy (the caller's own when the features came quad-planar), its tap table where `acc` would be
+            rc = launched(quad ? launch_quad_transpose(features, ws, p.B * p.V * (p.C / 4), p.H, p.W, make_gate(p, true), s)
+                               : launch_to_quad_planar(features, ws, p, s), "layout pass");
+            if (rc != MVHMR_OK) return rc;
+            if (!quad) {
+                rc = launched(launch_to_quad_planar_t(features, ws, p, s, false), "layout pass");
+                if (rc != MVHMR_OK) return rc;
+            }
+            hipError_t e = hipMemsetAsync(acc, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
+            if (e != hipSuccess) return launched(e, "gradient clear");
+            rc = launched(launch_bwd_brick(ws, grad_out, proj, coords, acc, p, s), "brick backward");
+            if (rc != MVHMR_OK) return rc;
+            rc = launched(launch_quad_grad_to_planar(acc, grad_features, p, s), "gradient layout pass");
+            if (rc != MVHMR_OK) return rc;
+            return launched(launch_bwd_plane(quad ? features : ws, grad_out, proj, coords, grad_features, acc, p, s), "plane backward");
+        }
         rc = launched(quad ? launch_quad_transpose(features, ws, p.B * p.V * (p.C / 4), p.H, p.W, make_gate(p, true), s)
                            : launch_to_quad_planar(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
@@ -392,6 +425,16 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
         rc = launched(launch_bwd_brick(ws, grad_out, proj, coords, gradK, p, s), "brick backward");
         if (rc != MVHMR_OK) return rc;
         return launched(launch_quad_grad_to_planar(gradK, grad_features, p, s), "gradient layout pass");
+    }
+    if (bwd_uses_plane(desc, p)) {
+        const void *featK = features;
+        if (desc->feat_layout == MVHMR_LAYOUT_BVCHW) {
+            rc = launched(launch_to_quad_planar_t(features, ws, p, s), "layout pass");
+            if (rc != MVHMR_OK) return rc;
+            featK = ws;
+            ws += brick_workspace_bytes(p);
+        }
+        return launched(launch_bwd_plane(featK, grad_out, proj, coords, grad_features, ws, p, s), "plane backward");
     }
     const void *featT = features;
     if (desc->feat_layout != MVHMR_LAYOUT_BVHWC) {

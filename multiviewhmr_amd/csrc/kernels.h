@@ -54,9 +54,16 @@ bool brick_fwd_supported(const Problem &p);
 bool brick_bwd_supported(const Problem &p);
 size_t brick_workspace_bytes(const Problem &p);
 hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, hipStream_t s);
-hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s);
+hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s, bool brick_side = true);
 hipError_t launch_fwd_brick(const void *featK, const float *proj, const Coords &coords, void *out, const Problem &p,
                             hipStream_t s);
+
+// plane backward (unproject_plane_bwd.hip): the gradient plane of one (sample, view, channel quad) accumulated in LDS, no global
+// atomics; the gather family's backward for planar / quad-planar features whose maps fit (Hf * (Wf | 1) * 16 B of LDS)
+bool plane_bwd_supported(const Problem &p);
+size_t plane_table_bytes(const Problem &p);
+hipError_t launch_bwd_plane(const void *featK, const void *grad_out, const float *proj, const Coords &coords, void *grad_features,
+                            void *table, const Problem &p, hipStream_t s);
 
 // Geometry gate.  Counts the bricks whose pooled tap windows would not fit (from the projections of each brick's 8 corner
 // voxels; speed heuristic only) into *count (zeroed by the caller).  GateGeom describes the bricks and windows of the kernel

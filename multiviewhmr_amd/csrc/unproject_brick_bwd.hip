@@ -22,6 +22,13 @@
 
 namespace mvhmr {
 
+// Timing-only ablations for scripts/exp (never defined in the product build): bit 0 no flush atomics, 1 plain stores instead of the
+// flush atomics, 2 no LDS adds
+#ifndef MVHMR_EXP_BWD
+#define MVHMR_EXP_BWD 0
+#endif
+constexpr int kExpB = MVHMR_EXP_BWD;
+
 // LDS: [ feature buffer 0 | feature buffer 1 | 4 gradient planes | BrickShared ]
 //   feature buffer = kZeroBytes of zeros + cap 16-B slots (as in the forward)
 //   gradient plane = (kZeroSlots + cap) floats; the first kZeroSlots only ever receive +0 (samples that are identically zero)
@@ -344,7 +351,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                     const int r1 = r0 + ws[v] * 4;
                     // lanes whose sample is identically zero add nothing: parked on the zero slot they would all hit ONE
                     // address, and same-address LDS atomics serialise (2 cycles per lane)
-                    if ((valid >> v) & 1u) {
+                    if (((valid >> v) & 1u) && !(kExpB & 4)) {
                         const float d = ds[i][v] * scale[i];
                         int *p0 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r0);
                         int *p1 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r1);
@@ -375,8 +382,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                     const int iv = *pl;
                     *pl = 0;                                                      // ready for the next quad
                     const bool add = (off & 1u) && (iv != 0 || inv_ch != inv_ch);   // poisoned channel (inv_ch is NaN): every live pixel
-                    if (__builtin_amdgcn_ballot_w64(add) != 0) {                   // wave-uniform: the instruction is issued or not
-                        if (add) atomicAdd(gq + (off >> 2) + ch, (float)iv * inv_ch);
+                    if (__builtin_amdgcn_ballot_w64(add) != 0 && !(kExpB & 1)) {    // wave-uniform: the instruction is issued or not
+                        if constexpr (kExpB & 2) { if (add) __builtin_nontemporal_store((float)iv * inv_ch, gq + (off >> 2) + ch); }
+                        else if (add) atomicAdd(gq + (off >> 2) + ch, (float)iv * inv_ch);
                         ++n_at;
                     }
                 }

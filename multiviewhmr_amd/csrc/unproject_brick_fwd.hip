@@ -89,19 +89,20 @@ k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, in
             d[(long long)x * H + y0 + ty] = make_float4(band[ty * ldw + x], band[(32 + ty) * ldw + x], band[(64 + ty) * ldw + x], band[(96 + ty) * ldw + x]);
 }
 
-hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s)
+hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s, bool brick_side)
 {
     if (p.C % 4) return hipErrorNotSupported;
+    const Gate gate = make_gate(p, brick_side);
     const size_t band_bytes = (size_t)4 * 32 * (p.W | 1) * sizeof(float);
     if (band_bytes <= 64 * 1024) {                                               // 2+ blocks per CU
         const dim3 grid((p.H + 31) / 32, p.C / 4, p.B * p.V);
-        if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t_band<__half>, grid, dim3(512), band_bytes, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
-        else hipLaunchKernelGGL(k_to_quad_planar_t_band<float>, grid, dim3(512), band_bytes, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
+        if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t_band<__half>, grid, dim3(512), band_bytes, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, gate);
+        else hipLaunchKernelGGL(k_to_quad_planar_t_band<float>, grid, dim3(512), band_bytes, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, gate);
         return hipGetLastError();
     }
     const dim3 grid(((p.W + 31) / 32) * ((p.H + 31) / 32), p.C / 4, p.B * p.V);
-    if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
-    else hipLaunchKernelGGL(k_to_quad_planar_t<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, make_gate(p, true));
+    if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, gate);
+    else hipLaunchKernelGGL(k_to_quad_planar_t<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, gate);
     return hipGetLastError();
 }
 

@@ -73,3 +73,24 @@ def test_check_loops_covers_the_backward_accumulation_loop(tmp_path):
     rules = ("k_bwd_brick:ds_add_u32",)
     assert _run("check_loops.py", str(ok), rules).returncode == 0
     assert _run("check_loops.py", str(bad), rules).returncode == 1
+
+
+def test_plane_backward_has_no_global_atomics_in_its_isa(tmp_path):
+    """the coarse-grid backward accumulates in LDS and writes plain stores.  Disassemble the unit for gfx950 (hipcc
+    cross-compiles without a GPU) and look at the k_bwd_plane functions."""
+    asm = tmp_path / "plane.s"
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
+                           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only", "-o", str(asm),
+                           os.path.join(CSRC, "unproject_plane_bwd.hip")], stderr=subprocess.DEVNULL)
+    inside, funcs, adds = None, 0, 0
+    for line in asm.read_text().splitlines():
+        ls = line.strip()
+        if ls.startswith("_ZN5mvhmr") and "k_bwd_plane" in ls and ls.endswith(":") is False and ":" in ls:
+            inside = ls.split(":")[0]
+            funcs += 1
+        elif ls.startswith(".Lfunc_end"):
+            inside = None
+        elif inside and not ls.startswith(";"):
+            assert "global_atomic" not in ls and "buffer_atomic" not in ls and "flat_atomic" not in ls, (inside, ls)
+            adds += ls.startswith("ds_add_u32")
+    assert funcs >= 12 and adds >= 16 * funcs                                     # 4 methods x 3 view counts x storage types; 16 LDS adds each
