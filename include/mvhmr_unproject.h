@@ -51,7 +51,12 @@ typedef enum mvhmr_agg_t {
 /* storage type of features / out / grad_out / grad_features.  Coordinates, projection matrices, tap
  * weights, the cross-view softmax and all accumulation are always fp32.  The reference is fp32 only;
  * MVHMR_F16 is this library's storage mode (SURVEY.md 8d "fp16 convention"). */
-typedef enum mvhmr_dtype_t { MVHMR_F32 = 0, MVHMR_F16 = 1 } mvhmr_dtype_t;
+typedef enum mvhmr_dtype_t {
+    MVHMR_F32 = 0,
+    MVHMR_F16 = 1,
+    MVHMR_BF16 = 2  /* out_dtype only, with fp32 features: the volume (and grad_out) stored as bf16 for a half-precision consumer
+                       (models/regressor.py:70-87 under autocast); round to nearest even at the store, NaN stays NaN */
+} mvhmr_dtype_t;
 
 /* memory layout of `features` (and of `grad_features`) */
 typedef enum mvhmr_layout_t {

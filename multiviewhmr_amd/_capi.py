@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(PKG, "lib", "libmvhmr_unproject.so")
 ABI_VERSION = 2
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH = range(5)
 AGG = {"softmax": 0, "sum": 1, "mean": 2, "max": 3}
-F32, F16 = 0, 1
+F32, F16, BF16 = 0, 1, 2
 LAYOUT_BVCHW, LAYOUT_BVHWC, LAYOUT_QUAD = 0, 1, 2
 VARIANT = {"auto": 0, "gather": 1, "brick": 2}
 

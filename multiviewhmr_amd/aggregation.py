@@ -49,7 +49,9 @@ def _dtype_code(dt):
         return _capi.F32
     if dt == torch.float16:
         return _capi.F16
-    raise RuntimeError("unprojection: features / volume must be float32 or float16, got %s" % dt)
+    if dt == torch.bfloat16:
+        return _capi.BF16                                # volume only (out_dtype with float32 features); the library checks the pairing
+    raise RuntimeError("unprojection: features / volume must be float32 or float16 (volume: also bfloat16), got %s" % dt)
 
 
 def _make_desc(features, coord_volumes, method, out_dtype, layout, variant):
@@ -116,7 +118,8 @@ def unprojection(features, proj_matricies, coord_volumes, aggregation_method='so
     coord_volumes   (B, X, Y, Z, 3) -- voxel centres in world units
     aggregation_method  'softmax' | 'sum' | 'mean' | 'max'; anything else -> ValueError (aggregation.py:85)
     returns         a new (B, C, X, Y, Z) tensor on features.device, float32 like the reference (aggregation.py:25)
-                    unless out_dtype is given (float16 features default to a float16 volume)
+                    unless out_dtype is given (float16 features default to a float16 volume; float32 features may ask for a
+                    bfloat16 volume -- what a half-precision consumer reads -- and then take a bfloat16 grad_out)
 
     `out_dtype` and `variant` ('auto' | 'gather' | 'brick') are keyword-only extensions.
     """
@@ -266,7 +269,7 @@ class _FusedAggregate(torch.autograd.Function):
     gradients are three GEMMs on it."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, proj, rot, center, position, sides, vol, method):
+    def forward(ctx, x, weight, bias, proj, rot, center, position, sides, vol, method, out_dtype=torch.float32):
         L = _capi.lib()
         B, V, Cin, Hf, Wf = x.shape
         Cout = weight.shape[0]
@@ -279,8 +282,8 @@ class _FusedAggregate(torch.autograd.Function):
             quad = torch.empty(B * V * Cout * Hf * Wf, dtype=torch.float32, device=dev)
             _capi.check(L.mvhmr_conv1x1_to_quad(_ptr(x), _ptr(w2), _ptr(bias) if bias is not None else ctypes.c_void_p(0), _ptr(quad),
                                                 B * V, Cin, Cout, Hf, Wf, _stream(dev)))
-            desc = _make_desc(torch.empty((B, V, Cout, Hf, Wf), dtype=torch.float32, device="meta"), vol, method, torch.float32, _capi.LAYOUT_QUAD, _capi.VARIANT["auto"])
-            out = torch.empty((B, Cout) + tuple(vol), dtype=torch.float32, device=dev)
+            desc = _make_desc(torch.empty((B, V, Cout, Hf, Wf), dtype=torch.float32, device="meta"), vol, method, out_dtype, _capi.LAYOUT_QUAD, _capi.VARIANT["auto"])
+            out = torch.empty((B, Cout) + tuple(vol), dtype=out_dtype, device=dev)
             ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), dev)
             _capi.check(L.mvhmr_unproject_forward_cuboid(ctypes.byref(desc), _ptr(quad), _ptr(proj), _ptr(rot), _ptr(center), pos, sid,
                                                          _ptr(out), wsp, 0 if ws is None else ws.numel(), _stream(dev)))
@@ -324,7 +327,7 @@ class _FusedAggregate(torch.autograd.Function):
                 gw = torch.einsum("nop,nip->oi", gy, xf).view(ctx.wshape)
             if want_b:
                 gb = gy.sum(dim=(0, 2))
-        return gx, gw, gb, None, None, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None, None, None
 
 
 def pack_cameras(cameras, device):
@@ -361,7 +364,7 @@ class VolumeGenerator(nn.Module):
 
     def __init__(self, volume_size=64, input_channels=256, output_channels=32, cuboid_side=2500.0,
                  aggregation_method='softmax', use_triangulation=False, kind='mpii', device='cuda',
-                 dataset='human36m', **kwargs):
+                 dataset='human36m', volume_dtype=None, **kwargs):
         # **kwargs swallows unknown keywords exactly like the reference (quirk Q5: build_volume_generator
         # passes volume_aggregation_method=, so aggregation_method keeps its default)
         super().__init__()
@@ -372,6 +375,7 @@ class VolumeGenerator(nn.Module):
         self.use_triangulation = use_triangulation
         self.kind = kind
         self.dataset = dataset
+        self.volume_dtype = volume_dtype  # extension: None = float32 like the reference; torch.bfloat16 / float16 for a half-precision consumer
         self.fused_conv = True            # 1x1 conv + layout pass as one MFMA GEMM wherever its shapes allow (see _fused_path_applies)
         self.to(device)
 
@@ -453,14 +457,14 @@ class VolumeGenerator(nn.Module):
             # 1x1 conv and layout pass in one MFMA GEMM, its output only ever exists in the layout the brick forward stages
             conv = self.process_feature[0]
             return _FusedAggregate.apply(features, conv.weight, conv.bias, proj, rots, centers, tuple(cub.position), tuple(cub.sides),
-                                         (S, S, S), _capi.AGG[self.aggregation_method])
+                                         (S, S, S), _capi.AGG[self.aggregation_method], self.volume_dtype or torch.float32)
 
         features = features.view(-1, *features.shape[2:])
         features = self.process_feature(features)
         features = features.view(batch_size, n_views, *features.shape[1:])
         # the coordinate volumes (aggregation.py:138-187) are never materialised: the kernels evaluate the cuboid recipe per voxel
         return unprojection_cuboid(features, proj, rots, centers, cub.position, cub.sides, (S, S, S),
-                                   aggregation_method=self.aggregation_method)
+                                   aggregation_method=self.aggregation_method, out_dtype=self.volume_dtype)
 
     def _fused_path_applies(self, features, S):
         """The fused conv writes the quad-planar layout, which the un-projection consumes for every geometry (brick kernels as it
@@ -469,6 +473,8 @@ class VolumeGenerator(nn.Module):
         fused GEMM takes and one whose quad-planar copy the un-projection (forward and backward) accepts."""
         if not self.fused_conv or not features.is_cuda or features.dtype != torch.float32 or self.aggregation_method not in _METHODS:
             return False
+        if self.volume_dtype not in (None, torch.float32, torch.bfloat16):
+            return False                                                          # fp32 conv output with an fp16 volume: not a storage mode of the library
         conv = self.process_feature[0]
         params = [conv.weight] + ([conv.bias] if conv.bias is not None else [])
         if any(t.dtype != torch.float32 or t.device != features.device for t in params):
@@ -479,7 +485,7 @@ class VolumeGenerator(nn.Module):
         if not L.mvhmr_conv1x1_to_quad_supported(Cin, Cout, Hf, Wf):
             return False
         meta = torch.empty((B, V, Cout, Hf, Wf), dtype=torch.float32, device="meta")
-        desc = _make_desc(meta, (S, S, S), _capi.AGG[self.aggregation_method], torch.float32, _capi.LAYOUT_QUAD, _capi.VARIANT["auto"])
+        desc = _make_desc(meta, (S, S, S), _capi.AGG[self.aggregation_method], self.volume_dtype or torch.float32, _capi.LAYOUT_QUAD, _capi.VARIANT["auto"])
         return L.mvhmr_unproject_selected_variant(ctypes.byref(desc)) > 0 and L.mvhmr_unproject_backward_supported(ctypes.byref(desc)) == 1
 
 

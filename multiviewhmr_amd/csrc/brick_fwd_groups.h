@@ -201,8 +201,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
                 __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, 18);
             } else {
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                const __half2 lo = __floats2half2_rn(res[0], res[1]), hi = __floats2half2_rn(res[2], res[3]);
-                const u32x2 d = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+                const u32x2 d = {pack2<TO>(res[0], res[1]), pack2<TO>(res[2], res[3])};
                 __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)st_off, 0, 18);
             }
         };

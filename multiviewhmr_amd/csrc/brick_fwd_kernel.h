@@ -285,8 +285,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off[u], 0, 18);   // nt sc1: best of the five policies (r02 ablations)
             } else {
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                const __half2 lo = __floats2half2_rn(res[0], res[1]), hi = __floats2half2_rn(res[2], res[3]);   // round to nearest even
-                const u32x2 d = {__builtin_bit_cast(unsigned, lo), __builtin_bit_cast(unsigned, hi)};
+                const u32x2 d = {pack2<TO>(res[0], res[1]), pack2<TO>(res[2], res[3])};
                 __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)st_off[u], 0, 18);
             }
         };
@@ -435,11 +434,13 @@ hipError_t launch_fwd_method(const void *featK_, const float *proj, const Coords
     const float4 *featK = static_cast<const float4 *>(featK_);
 #define MVHMR_FWD_CASE(NVIEWS, NTHR, NV)                                                                                                 \
     if (p.V == NVIEWS && nvox == NV)                                                                                                      \
-        return p.out_f16 ? launch_fwd_instance<METHOD, NVIEWS, NTHR, __half, NV>(featK, proj, coords, (__half *)out, p, s)               \
-                         : launch_fwd_instance<METHOD, NVIEWS, NTHR, float, NV>(featK, proj, coords, (float *)out, p, s)
+        return p.out_f16    ? launch_fwd_instance<METHOD, NVIEWS, NTHR, __half, NV>(featK, proj, coords, (__half *)out, p, s)            \
+               : p.out_bf16 ? launch_fwd_instance<METHOD, NVIEWS, NTHR, bf16_t, NV>(featK, proj, coords, (bf16_t *)out, p, s)            \
+                            : launch_fwd_instance<METHOD, NVIEWS, NTHR, float, NV>(featK, proj, coords, (float *)out, p, s)
     if (brick_fwd_grouped(p))
-        return p.out_f16 ? launch_fwd_groups_instance<METHOD, 8, __half>(featK, proj, coords, (__half *)out, p, s)
-                         : launch_fwd_groups_instance<METHOD, 8, float>(featK, proj, coords, (float *)out, p, s);
+        return p.out_f16    ? launch_fwd_groups_instance<METHOD, 8, __half>(featK, proj, coords, (__half *)out, p, s)
+               : p.out_bf16 ? launch_fwd_groups_instance<METHOD, 8, bf16_t>(featK, proj, coords, (bf16_t *)out, p, s)
+                            : launch_fwd_groups_instance<METHOD, 8, float>(featK, proj, coords, (float *)out, p, s);
     MVHMR_FWD_CASE(2, 1024, 1); MVHMR_FWD_CASE(2, 1024, 2);
     MVHMR_FWD_CASE(4, 1024, 1); MVHMR_FWD_CASE(4, 1024, 2);
     MVHMR_FWD_CASE(8, 512, 1);  MVHMR_FWD_CASE(8, 512, 2);

@@ -64,8 +64,12 @@ int check_desc(const mvhmr_unproject_desc *d, Problem *p)
                     d->channels, d->feat_h, d->feat_w, d->vol_x, d->vol_y, d->vol_z);
     if (d->method < MVHMR_AGG_SOFTMAX || d->method > MVHMR_AGG_MAX)
         return fail(MVHMR_ERR_INVALID_ARGUMENT, "Unknown aggregation_method: %d", d->method);
-    if (d->feat_dtype < 0 || d->feat_dtype > MVHMR_F16 || d->out_dtype < 0 || d->out_dtype > MVHMR_F16)
+    if (d->feat_dtype < 0 || d->feat_dtype > MVHMR_BF16 || d->out_dtype < 0 || d->out_dtype > MVHMR_BF16)
         return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown dtype (feat %d, out %d)", d->feat_dtype, d->out_dtype);
+    if (d->feat_dtype == MVHMR_BF16)
+        return fail(MVHMR_ERR_UNSUPPORTED, "bf16 is a storage type of the volume only (out_dtype); features are fp32 or fp16");
+    if (d->out_dtype == MVHMR_BF16 && d->feat_dtype != MVHMR_F32)
+        return fail(MVHMR_ERR_UNSUPPORTED, "a bf16 volume needs fp32 features");
     if (d->feat_layout < 0 || d->feat_layout > MVHMR_LAYOUT_QUAD) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown feature layout %d", d->feat_layout);
     if (d->variant < 0 || d->variant > MVHMR_VARIANT_BRICK) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", d->variant);
     if (d->views > kMaxViews) return fail(MVHMR_ERR_UNSUPPORTED, "at most %d views are supported (got %d)", kMaxViews, d->views);
@@ -78,6 +82,7 @@ int check_desc(const mvhmr_unproject_desc *d, Problem *p)
     p->method = d->method;
     p->feat_f16 = d->feat_dtype == MVHMR_F16;
     p->out_f16 = d->out_dtype == MVHMR_F16;
+    p->out_bf16 = d->out_dtype == MVHMR_BF16;
     if ((long long)p->H * p->W * p->C4 >= (1ll << 31))
         return fail(MVHMR_ERR_UNSUPPORTED, "one feature map (Hf*Wf*C = %lld elements) exceeds 32-bit tap offsets", (long long)p->H * p->W * p->C4);
     if (d->feat_layout != MVHMR_LAYOUT_BVCHW && p->C4 != p->C)

@@ -254,12 +254,32 @@ template <> struct Vec4<__half> {
     }
 };
 
+// bf16 is a storage type of the VOLUME only (out / grad_out with fp32 features): clang's native __bf16, whose conversion from float is
+// v_cvt_pk_bf16_f32 on gfx950 (round to nearest even, NaN stays NaN)
+typedef __bf16 bf16_t;
+
 template <typename T> __device__ __forceinline__ float to_f32(T x);
 template <> __device__ __forceinline__ float to_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ float to_f32<__half>(__half x) { return __half2float(x); }
+template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
 template <> __device__ __forceinline__ __half from_f32<__half>(float x) { return __float2half_rn(x); }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
+
+// two floats -> one dword of a 16-bit storage type (low half = a)
+template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
+template <> __device__ __forceinline__ unsigned pack2<__half>(float a, float b)
+{
+    const __half2 h = __floats2half2_rn(a, b);                                   // round to nearest even
+    return __builtin_bit_cast(unsigned, h);
+}
+template <> __device__ __forceinline__ unsigned pack2<bf16_t>(float a, float b)
+{
+    typedef bf16_t bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 h = {(bf16_t)a, (bf16_t)b};
+    return __builtin_bit_cast(unsigned, h);
+}
 
 __device__ __forceinline__ int uniform(int x) { return __builtin_amdgcn_readfirstlane(x); }
 __device__ __forceinline__ float uniform(float x)

@@ -14,6 +14,7 @@ struct Problem {
     int C4;                   // channels rounded up to a multiple of 4 (channels-last row length)
     int method;               // AGG_*
     int feat_f16, out_f16;    // storage types
+    int out_bf16 = 0;         // the volume (out / grad_out) is bf16; features are fp32 then
     // Geometry gate (AUTO on planar input, shapes both variants serve): `gate_count` points at a device counter of
     // bricks whose windows overflow LDS (k_brick_gate); a gated kernel runs when (count <= gate_limit) == wants_brick
     // and returns at once otherwise.  Null = no gate.

@@ -484,6 +484,7 @@ hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float
 {
     if (!brick_bwd_supported(p)) return hipErrorNotSupported;
     const float4 *fk = static_cast<const float4 *>(featK);
+    if (p.out_bf16) return launch_bt<bf16_t>(fk, static_cast<const bf16_t *>(grad_out), proj, coords, gradK, p, s);
     return p.out_f16 ? launch_bt<__half>(fk, static_cast<const __half *>(grad_out), proj, coords, gradK, p, s)
                      : launch_bt<float>(fk, static_cast<const float *>(grad_out), proj, coords, gradK, p, s);
 }
@@ -500,7 +501,7 @@ hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Probl
 
 bool brick_bwd_supported(const Problem &p)
 {
-    if (p.feat_f16 != p.out_f16) return false;                            // fp32 or fp16 storage throughout; mixed -> gather
+    if (p.feat_f16 != p.out_f16) return false;                            // fp32 or fp16 storage throughout (or fp32 features with a bf16 volume); other mixes -> gather
     if (p.V != 2 && p.V != 4 && p.V != 8) return false;
     const int nt = p.V == 8 ? kNTb8 : kNTb;
     if (p.C % 4) return false;

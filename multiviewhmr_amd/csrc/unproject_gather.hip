@@ -54,6 +54,11 @@ __device__ __forceinline__ void store_streaming(__half *p, float v)
     __builtin_nontemporal_store(__half_as_ushort(__float2half_rn(v)), reinterpret_cast<unsigned short *>(p));
 }
 
+__device__ __forceinline__ void store_streaming(bf16_t *p, float v)
+{
+    __builtin_nontemporal_store(__builtin_bit_cast(unsigned short, (bf16_t)v), reinterpret_cast<unsigned short *>(p));
+}
+
 struct UTap { int o00, o01, o10, o11; float w00, w01, w10, w11; };
 __device__ __forceinline__ UTap uniform_rec(const TapRec &r)
 {
@@ -427,6 +432,7 @@ static hipError_t fwd_dispatch_m(const TF *featT, const float *proj, const Coord
 hipError_t launch_fwd_gather(const void *featT, const float *proj, const Coords &coords, void *out, const Problem &p,
                              hipStream_t s)
 {
+    if (p.out_bf16) return p.feat_f16 ? hipErrorNotSupported : fwd_dispatch_m((const float *)featT, proj, coords, (bf16_t *)out, p, s);
     if (!p.feat_f16 && !p.out_f16) return fwd_dispatch_m((const float *)featT, proj, coords, (float *)out, p, s);
     if (p.feat_f16 && p.out_f16) return fwd_dispatch_m((const __half *)featT, proj, coords, (__half *)out, p, s);
     if (p.feat_f16 && !p.out_f16) return fwd_dispatch_m((const __half *)featT, proj, coords, (float *)out, p, s);
@@ -470,6 +476,7 @@ static hipError_t bwd_dispatch_m(const TO *go_, const TF *featT, const float *pr
 hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const float *proj, const Coords &coords,
                              float *gradT, const Problem &p, hipStream_t s)
 {
+    if (p.out_bf16) return p.feat_f16 ? hipErrorNotSupported : bwd_dispatch_m((const bf16_t *)grad_out, (const float *)featT, proj, coords, gradT, p, s);
     if (!p.feat_f16 && !p.out_f16) return bwd_dispatch_m((const float *)grad_out, (const float *)featT, proj, coords, gradT, p, s);
     if (p.feat_f16 && p.out_f16) return bwd_dispatch_m((const __half *)grad_out, (const __half *)featT, proj, coords, gradT, p, s);
     if (p.feat_f16 && !p.out_f16) return bwd_dispatch_m((const float *)grad_out, (const __half *)featT, proj, coords, gradT, p, s);

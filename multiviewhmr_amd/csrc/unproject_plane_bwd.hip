@@ -360,6 +360,7 @@ hipError_t launch_bwd_plane(const void *featK, const void *grad_out, const float
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const float4 *fk = static_cast<const float4 *>(featK);
+    if (p.out_bf16) return p.feat_f16 ? hipErrorNotSupported : launch_plane_method<bf16_t, float>(fk, (const bf16_t *)grad_out, tabW, tabX, cmax, (float *)grad_features, p, s);
     if (!p.out_f16 && !p.feat_f16) return launch_plane_method<float, float>(fk, (const float *)grad_out, tabW, tabX, cmax, (float *)grad_features, p, s);
     if (p.out_f16 && p.feat_f16) return launch_plane_method<__half, __half>(fk, (const __half *)grad_out, tabW, tabX, cmax, (__half *)grad_features, p, s);
     if (!p.out_f16 && p.feat_f16) return launch_plane_method<float, __half>(fk, (const float *)grad_out, tabW, tabX, cmax, (__half *)grad_features, p, s);

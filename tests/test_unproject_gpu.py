@@ -1104,3 +1104,42 @@ def test_config1_backward_plane_kernel(config1, gpu):
     gref = cport.backward(g[5:6, chans].cpu().numpy(), f[5:6, :, chans].detach().cpu().numpy(), p[5:6].cpu().numpy(), c[5:6].cpu().numpy(), "softmax")
     record_err("configs[1] bwd (sample 5, 8 channels)", _err(f.grad[5:6, :, chans].cpu().numpy(), gref), _bound(gref))
     assert float(f.grad[:5].abs().max()) == 0.0 and float(f.grad[5, :, 4:128].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------ bf16 volume (the consumer's dtype)
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_bf16_volume_forward_and_backward(variant, gpu):
+    """out_dtype = bfloat16 with fp32 features: the volume is the fp32 result rounded once (half a bf16 ulp: up to 2^-8 relative), and the
+    backward takes a bf16 grad_out: fp32 arithmetic on exactly those values (checked against the oracle fed the rounded grad_out)"""
+    feats, proj, coords = _ring_problem(B=2, V=4, C=16, H=32, W=32, vol=(8, 8, 32), seed=23)
+    f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    ref = cport.forward(feats, proj, coords, "softmax")
+    out = aggregation.unprojection(f, p, c, out_dtype=torch.bfloat16, variant=variant)
+    assert out.dtype == torch.bfloat16
+    record_err("bf16 volume fwd (%s)" % variant, _err(out.float().detach().cpu().numpy(), ref), TOL + np.abs(ref).max() * 2.0 ** -8)
+    o32 = aggregation.unprojection(f.detach(), p, c, variant=variant)
+    assert torch.equal(out.detach(), o32.to(torch.bfloat16))                       # exactly the fp32 volume, rounded to nearest even
+    go = torch.randn(out.shape, device=gpu, generator=torch.Generator(device=gpu).manual_seed(4)).to(torch.bfloat16)
+    out.backward(go)
+    gref = cport.backward(go.float().cpu().numpy(), feats, proj, coords, "softmax")
+    assert f.grad.dtype == torch.float32
+    record_err("bf16 volume bwd (%s)" % variant, _err(f.grad.cpu().numpy(), gref), _bound(gref))
+
+
+def test_bf16_volume_through_the_volume_generator(gpu):
+    """VolumeGenerator(volume_dtype=torch.bfloat16): fused and unfused routes give the bf16 rounding of their fp32 volumes"""
+    d = load_golden("volgen", "train_mpii")
+    gen, batch, seed = _rebuild(d, gpu)
+    np.random.seed(seed)
+    with torch.no_grad():
+        a = gen(_dev(d, "features_in", gpu), _dev(d, "proj_org", gpu), batch)
+    gen.volume_dtype = torch.bfloat16
+    np.random.seed(seed)
+    with torch.no_grad():
+        b = gen(_dev(d, "features_in", gpu), _dev(d, "proj_org", gpu), batch)
+    assert b.dtype == torch.bfloat16 and torch.equal(b, a.to(torch.bfloat16))
+    record_err("volgen bf16 volume train_mpii", _err(b.float().cpu().numpy(), d["volume"]), TOL + np.abs(d["volume"]).max() * 2.0 ** -8)
+    with pytest.raises(RuntimeError):                                              # bf16 is not a feature storage type
+        aggregation.unprojection(_dev(d, "features_in", gpu).to(torch.bfloat16)[:, :, :4], _dev(d, "proj_org", gpu),
+                                 torch.zeros(a.shape[0], 4, 4, 4, 3, device=gpu))
