@@ -70,42 +70,75 @@ def _make_desc(features, coord_volumes, method, out_dtype, layout, variant):
     return d
 
 
-class _Unprojection(torch.autograd.Function):
-    """forward -> mvhmr_unproject_forward, backward -> mvhmr_unproject_backward (grad w.r.t. features only:
-    proj_matricies and coord_volumes come from numpy / arange in the caller and never require grad)."""
+# The op is registered with torch.library (mvhmr::unprojection / mvhmr::unprojection_backward): eager calls dispatch to the C ABI,
+# FakeTensor / meta calls to the shape functions, autograd to the registered formula -- so torch.compile and AOT autograd see one
+# opaque node with a known output shape and a known backward instead of a Python autograd.Function they cannot trace into.
+_DTYPES = {_capi.F32: torch.float32, _capi.F16: torch.float16, _capi.BF16: torch.bfloat16}
 
-    @staticmethod
-    def forward(ctx, features, proj, coords, method, out_dtype, variant):
-        L = _capi.lib()
-        layout = _capi.LAYOUT_BVHWC if _is_channels_last5(features) else _capi.LAYOUT_BVCHW
-        if layout == _capi.LAYOUT_BVCHW:
-            features = features.contiguous()
-        desc = _make_desc(features, coords, method, out_dtype, layout, variant)
-        B, C = features.shape[0], features.shape[2]
-        with torch.cuda.device(features.device):
-            out = torch.empty((B, C) + tuple(coords.shape[1:4]), dtype=out_dtype, device=features.device)
-            ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), features.device)
-            _capi.check(L.mvhmr_unproject_forward(ctypes.byref(desc), _ptr(features), _ptr(proj), _ptr(coords), _ptr(out),
-                                                  wsp, 0 if ws is None else ws.numel(), _stream(features.device)))
-        ctx.save_for_backward(features, proj, coords)
-        ctx.desc = desc
-        return out
 
-    @staticmethod
-    def backward(ctx, grad_out):
-        features, proj, coords = ctx.saved_tensors
-        if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None, None
-        L = _capi.lib()
-        desc = ctx.desc
-        grad_out = grad_out.contiguous()
-        with torch.cuda.device(features.device):
-            grad_features = torch.empty_like(features)           # keeps the (possibly channels-last) strides
-            ws, wsp = _workspace(L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc)), features.device)
-            _capi.check(L.mvhmr_unproject_backward(ctypes.byref(desc), _ptr(grad_out), _ptr(features), _ptr(proj), _ptr(coords),
-                                                   _ptr(grad_features), wsp, 0 if ws is None else ws.numel(),
-                                                   _stream(features.device)))
-        return grad_features, None, None, None, None, None
+def _op_forward(features, proj, coords, method, out_dtype, variant):
+    L = _capi.lib()
+    layout = _capi.LAYOUT_BVHWC if _is_channels_last5(features) else _capi.LAYOUT_BVCHW
+    if layout == _capi.LAYOUT_BVCHW:
+        features = features.contiguous()
+    desc = _make_desc(features, coords, method, _DTYPES[out_dtype], layout, variant)
+    B, C = features.shape[0], features.shape[2]
+    with torch.cuda.device(features.device):
+        out = torch.empty((B, C) + tuple(coords.shape[1:4]), dtype=_DTYPES[out_dtype], device=features.device)
+        ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), features.device)
+        _capi.check(L.mvhmr_unproject_forward(ctypes.byref(desc), _ptr(features), _ptr(proj), _ptr(coords), _ptr(out),
+                                              wsp, 0 if ws is None else ws.numel(), _stream(features.device)))
+    return out
+
+
+def _op_backward(grad_out, features, proj, coords, method, out_dtype, variant):
+    """gradient w.r.t. features only: proj_matricies and coord_volumes come from numpy / arange in the caller and never require grad"""
+    L = _capi.lib()
+    layout = _capi.LAYOUT_BVHWC if _is_channels_last5(features) else _capi.LAYOUT_BVCHW
+    if layout == _capi.LAYOUT_BVCHW:
+        features = features.contiguous()
+    desc = _make_desc(features, coords, method, _DTYPES[out_dtype], layout, variant)
+    grad_out = grad_out.contiguous()
+    with torch.cuda.device(features.device):
+        grad_features = torch.empty_like(features)               # keeps the (possibly channels-last) strides
+        ws, wsp = _workspace(L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc)), features.device)
+        _capi.check(L.mvhmr_unproject_backward(ctypes.byref(desc), _ptr(grad_out), _ptr(features), _ptr(proj), _ptr(coords),
+                                               _ptr(grad_features), wsp, 0 if ws is None else ws.numel(), _stream(features.device)))
+    return grad_features
+
+
+def _fake_forward(features, proj, coords, method, out_dtype, variant):
+    return features.new_empty((features.shape[0], features.shape[2]) + tuple(coords.shape[1:4]), dtype=_DTYPES[out_dtype])
+
+
+def _fake_backward(grad_out, features, proj, coords, method, out_dtype, variant):
+    return torch.empty_like(features)
+
+
+def _autograd_setup(ctx, inputs, output):
+    features, proj, coords, method, out_dtype, variant = inputs
+    ctx.save_for_backward(features, proj, coords)
+    ctx.args = (method, out_dtype, variant)
+
+
+def _autograd_backward(ctx, grad_out):
+    features, proj, coords = ctx.saved_tensors
+    g = torch.ops.mvhmr.unprojection_backward(grad_out, features, proj, coords, *ctx.args) if ctx.needs_input_grad[0] else None
+    return g, None, None, None, None, None
+
+
+def _register_ops():
+    sig = "(Tensor features, Tensor proj, Tensor coords, int method, int out_dtype, int variant) -> Tensor"
+    torch.library.define("mvhmr::unprojection", sig)
+    torch.library.define("mvhmr::unprojection_backward", "(Tensor grad_out, " + sig[1:])
+    torch.library.impl("mvhmr::unprojection", "CUDA")(_op_forward)
+    torch.library.impl("mvhmr::unprojection_backward", "CUDA")(_op_backward)
+    torch.library.register_fake("mvhmr::unprojection")(_fake_forward)
+    torch.library.register_fake("mvhmr::unprojection_backward")(_fake_backward)
+    torch.library.register_autograd("mvhmr::unprojection", _autograd_backward, setup_context=_autograd_setup)
+
+
+_register_ops()
 
 
 def unprojection(features, proj_matricies, coord_volumes, aggregation_method='softmax', *, out_dtype=None,
@@ -151,46 +184,72 @@ def unprojection(features, proj_matricies, coord_volumes, aggregation_method='so
         return torch.zeros((B, features.shape[2]) + tuple(coord_volumes.shape[1:4]), dtype=out_dtype, device=features.device)
     proj = proj_matricies.detach().to(torch.float32).contiguous()
     coords = coord_volumes.detach().to(torch.float32).contiguous()
-    return _Unprojection.apply(features, proj, coords, _capi.AGG[aggregation_method], out_dtype, _capi.VARIANT[variant])
+    return torch.ops.mvhmr.unprojection(features, proj, coords, _capi.AGG[aggregation_method], _dtype_code(out_dtype), _capi.VARIANT[variant])
 
 
-class _UnprojectionCuboid(torch.autograd.Function):
-    """The same kernels fed by the cuboid recipe instead of a coordinate tensor (mvhmr_unproject_*_cuboid)."""
+# The same kernels fed by the cuboid recipe instead of a coordinate tensor (mvhmr_unproject_*_cuboid), registered the same way
+# (mvhmr::unprojection_cuboid / mvhmr::unprojection_cuboid_backward).
+def _d3(values):
+    return (ctypes.c_double * 3)(*[float(x) for x in values])
 
-    @staticmethod
-    def forward(ctx, features, proj, rot, center, position, sides, vol, method, out_dtype, variant):
-        L = _capi.lib()
-        layout = _capi.LAYOUT_BVHWC if _is_channels_last5(features) else _capi.LAYOUT_BVCHW
-        if layout == _capi.LAYOUT_BVCHW:
-            features = features.contiguous()
-        desc = _make_desc(features, vol, method, out_dtype, layout, variant)
-        pos = (ctypes.c_double * 3)(*[float(x) for x in position])
-        sid = (ctypes.c_double * 3)(*[float(x) for x in sides])
-        B, C = features.shape[0], features.shape[2]
-        with torch.cuda.device(features.device):
-            out = torch.empty((B, C) + tuple(vol), dtype=out_dtype, device=features.device)
-            ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), features.device)
-            _capi.check(L.mvhmr_unproject_forward_cuboid(ctypes.byref(desc), _ptr(features), _ptr(proj), _ptr(rot), _ptr(center), pos, sid,
-                                                         _ptr(out), wsp, 0 if ws is None else ws.numel(), _stream(features.device)))
-        ctx.save_for_backward(features, proj, rot, center)
-        ctx.desc, ctx.pos, ctx.sid = desc, pos, sid
-        return out
 
-    @staticmethod
-    def backward(ctx, grad_out):
-        features, proj, rot, center = ctx.saved_tensors
-        if not ctx.needs_input_grad[0]:
-            return (None,) * 10
-        L = _capi.lib()
-        desc = ctx.desc
-        grad_out = grad_out.contiguous()
-        with torch.cuda.device(features.device):
-            grad_features = torch.empty_like(features)
-            ws, wsp = _workspace(L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc)), features.device)
-            _capi.check(L.mvhmr_unproject_backward_cuboid(ctypes.byref(desc), _ptr(grad_out), _ptr(features), _ptr(proj), _ptr(rot),
-                                                          _ptr(center), ctx.pos, ctx.sid, _ptr(grad_features), wsp,
-                                                          0 if ws is None else ws.numel(), _stream(features.device)))
-        return (grad_features,) + (None,) * 9
+def _opc_forward(features, proj, rot, center, position, sides, vol, method, out_dtype, variant):
+    L = _capi.lib()
+    layout = _capi.LAYOUT_BVHWC if _is_channels_last5(features) else _capi.LAYOUT_BVCHW
+    if layout == _capi.LAYOUT_BVCHW:
+        features = features.contiguous()
+    desc = _make_desc(features, vol, method, _DTYPES[out_dtype], layout, variant)
+    B, C = features.shape[0], features.shape[2]
+    with torch.cuda.device(features.device):
+        out = torch.empty((B, C) + tuple(vol), dtype=_DTYPES[out_dtype], device=features.device)
+        ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), features.device)
+        _capi.check(L.mvhmr_unproject_forward_cuboid(ctypes.byref(desc), _ptr(features), _ptr(proj), _ptr(rot), _ptr(center), _d3(position),
+                                                     _d3(sides), _ptr(out), wsp, 0 if ws is None else ws.numel(), _stream(features.device)))
+    return out
+
+
+def _opc_backward(grad_out, features, proj, rot, center, position, sides, vol, method, out_dtype, variant):
+    L = _capi.lib()
+    layout = _capi.LAYOUT_BVHWC if _is_channels_last5(features) else _capi.LAYOUT_BVCHW
+    if layout == _capi.LAYOUT_BVCHW:
+        features = features.contiguous()
+    desc = _make_desc(features, vol, method, _DTYPES[out_dtype], layout, variant)
+    grad_out = grad_out.contiguous()
+    with torch.cuda.device(features.device):
+        grad_features = torch.empty_like(features)
+        ws, wsp = _workspace(L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc)), features.device)
+        _capi.check(L.mvhmr_unproject_backward_cuboid(ctypes.byref(desc), _ptr(grad_out), _ptr(features), _ptr(proj), _ptr(rot), _ptr(center),
+                                                      _d3(position), _d3(sides), _ptr(grad_features), wsp, 0 if ws is None else ws.numel(),
+                                                      _stream(features.device)))
+    return grad_features
+
+
+def _opc_setup(ctx, inputs, output):
+    ctx.save_for_backward(*inputs[:4])
+    ctx.args = tuple(inputs[4:])
+
+
+def _opc_autograd(ctx, grad_out):
+    features, proj, rot, center = ctx.saved_tensors
+    g = torch.ops.mvhmr.unprojection_cuboid_backward(grad_out, features, proj, rot, center, *ctx.args) if ctx.needs_input_grad[0] else None
+    return (g,) + (None,) * 9
+
+
+def _register_cuboid_ops():
+    sig = "(Tensor features, Tensor proj, Tensor rot, Tensor center, float[] position, float[] sides, int[] vol, int method, int out_dtype, int variant) -> Tensor"
+    torch.library.define("mvhmr::unprojection_cuboid", sig)
+    torch.library.define("mvhmr::unprojection_cuboid_backward", "(Tensor grad_out, " + sig[1:])
+    torch.library.impl("mvhmr::unprojection_cuboid", "CUDA")(_opc_forward)
+    torch.library.impl("mvhmr::unprojection_cuboid_backward", "CUDA")(_opc_backward)
+    torch.library.register_fake("mvhmr::unprojection_cuboid")(
+        lambda features, proj, rot, center, position, sides, vol, method, out_dtype, variant:
+        features.new_empty((features.shape[0], features.shape[2]) + tuple(vol), dtype=_DTYPES[out_dtype]))
+    torch.library.register_fake("mvhmr::unprojection_cuboid_backward")(
+        lambda grad_out, features, proj, rot, center, position, sides, vol, method, out_dtype, variant: torch.empty_like(features))
+    torch.library.register_autograd("mvhmr::unprojection_cuboid", _opc_autograd, setup_context=_opc_setup)
+
+
+_register_cuboid_ops()
 
 
 def unprojection_cuboid(features, proj_matricies, rotations, centers, position, sides, volume_shape,
@@ -228,8 +287,8 @@ def unprojection_cuboid(features, proj_matricies, rotations, centers, position, 
     proj = proj_matricies.detach().to(device=dev, dtype=torch.float32).contiguous()
     rot = rotations.detach().to(device=dev, dtype=torch.float32).contiguous()
     cen = centers.detach().to(device=dev, dtype=torch.float32).contiguous()
-    return _UnprojectionCuboid.apply(features, proj, rot, cen, tuple(position), tuple(sides), vol, _capi.AGG[aggregation_method],
-                                     out_dtype, _capi.VARIANT[variant])
+    return torch.ops.mvhmr.unprojection_cuboid(features, proj, rot, cen, [float(x) for x in position], [float(x) for x in sides], list(vol),
+                                               _capi.AGG[aggregation_method], _dtype_code(out_dtype), _capi.VARIANT[variant])
 
 
 # --------------------------------------------------------------------------------------- caller side

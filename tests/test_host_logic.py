@@ -235,3 +235,24 @@ def test_device_projection_recipe_matches_the_host_one_on_cpu_tensors():
     host = aggregation.feature_level_projections(cams, (384, 320), (96, 80))
     dev = aggregation.feature_level_projections_device(aggregation.pack_cameras(cams, "cpu"), (384, 320), (96, 80))
     assert dev.dtype == torch.float32 and np.array_equal(dev.numpy(), host)
+
+
+def test_ops_are_registered_with_torch_library_and_trace_without_a_gpu():
+    """mvhmr::unprojection / ::unprojection_cuboid (+ _backward): shape functions and the autograd formula are registered, so FakeTensor
+    tracing (torch.compile / AOT autograd) sees one node with a known output and a known backward -- no HIP device needed for that"""
+    import torch
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from multiviewhmr_amd import aggregation, _capi  # noqa: F401  (registers the ops)
+    f = torch.empty(2, 4, 8, 24, 24, device="meta")
+    out = torch.ops.mvhmr.unprojection(f, torch.empty(2, 4, 3, 4, device="meta"), torch.empty(2, 8, 8, 32, 3, device="meta"), 0, _capi.BF16, 0)
+    assert tuple(out.shape) == (2, 8, 8, 8, 32) and out.dtype == torch.bfloat16
+    with FakeTensorMode():
+        f = torch.empty(2, 4, 8, 24, 24, requires_grad=True)
+        p = torch.empty(2, 4, 3, 4)
+        o = torch.ops.mvhmr.unprojection(f, p, torch.empty(2, 8, 8, 32, 3), 0, _capi.F32, 0)
+        o.sum().backward()
+        assert tuple(o.shape) == (2, 8, 8, 8, 32) and tuple(f.grad.shape) == tuple(f.shape)
+        f2 = torch.empty(2, 4, 8, 24, 24, requires_grad=True)
+        o2 = torch.ops.mvhmr.unprojection_cuboid(f2, p, torch.empty(2, 3, 3), torch.empty(2, 3), [0.0, 0.0, 0.0], [1.0, 1.0, 1.0], [4, 8, 32], 1, _capi.F32, 0)
+        o2.sum().backward()
+        assert tuple(o2.shape) == (2, 8, 4, 8, 32) and tuple(f2.grad.shape) == tuple(f2.shape)

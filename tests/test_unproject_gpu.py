@@ -1143,3 +1143,23 @@ def test_bf16_volume_through_the_volume_generator(gpu):
     with pytest.raises(RuntimeError):                                              # bf16 is not a feature storage type
         aggregation.unprojection(_dev(d, "features_in", gpu).to(torch.bfloat16)[:, :, :4], _dev(d, "proj_org", gpu),
                                  torch.zeros(a.shape[0], 4, 4, 4, 3, device=gpu))
+
+
+def test_unprojection_traces_under_torch_compile(gpu):
+    """The op is a torch.library custom op: AOT autograd (torch.compile, backend aot_eager: no code generator involved) captures
+    forward and backward as single nodes; the results are the eager ones bit for bit"""
+    feats, proj, coords = _ring_problem(B=2, V=4, C=8, H=24, W=24, vol=(8, 8, 32), seed=31)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+
+    def fn(f):
+        return aggregation.unprojection(2.0 * f, p, c, aggregation_method="softmax").sum(dim=1)
+
+    fe = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    oe = fn(fe)
+    go = torch.randn_like(oe)
+    oe.backward(go)
+    fc = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    oc = torch.compile(fn, backend="aot_eager", fullgraph=True)(fc)
+    oc.backward(go)
+    assert torch.equal(oc, oe)
+    record_err("torch.compile (aot_eager) vs eager, grad", float((fc.grad - fe.grad).abs().max()), 1e-5)
