@@ -1163,3 +1163,45 @@ def test_unprojection_traces_under_torch_compile(gpu):
     oc.backward(go)
     assert torch.equal(oc, oe)
     record_err("torch.compile (aot_eager) vs eager, grad", float((fc.grad - fe.grad).abs().max()), 1e-5)
+
+
+def test_plane_backward_storage_modes_and_quad_planar_features(gpu):
+    """The plane kernel behind every storage mode the gather family serves, and fed the caller's own quad-planar copy"""
+    shape = dict(B=2, V=4, C=8, H=40, W=56, vol=(12, 10, 9))
+    feats, proj, coords = _ring_problem(seed=19, **shape)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    go = np.random.default_rng(6).standard_normal((2, 8, 12, 10, 9), dtype=np.float32)
+    # fp16 storage throughout
+    f16 = torch.from_numpy(feats).to(gpu).half().requires_grad_(True)
+    g16 = torch.from_numpy(go).to(gpu).half()
+    aggregation.unprojection(f16, p, c, variant="gather").backward(g16)
+    gref = cport.backward(g16.float().cpu().numpy(), f16.detach().float().cpu().numpy(), proj, coords, "softmax")
+    record_err("plane bwd, fp16 storage", _err(f16.grad.float().cpu().numpy(), gref), TOL + np.abs(gref).max() * 2.0 ** -10)
+    # fp16 features, fp32 volume / grad_out
+    f16b = torch.from_numpy(feats).to(gpu).half().requires_grad_(True)
+    aggregation.unprojection(f16b, p, c, variant="gather", out_dtype=torch.float32).backward(torch.from_numpy(go).to(gpu))
+    gref = cport.backward(go, f16b.detach().float().cpu().numpy(), proj, coords, "softmax")
+    record_err("plane bwd, fp16 features + fp32 grad_out", _err(f16b.grad.float().cpu().numpy(), gref), TOL + np.abs(gref).max() * 2.0 ** -10)
+    # fp32 features, bf16 grad_out
+    f32 = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    gb = torch.from_numpy(go).to(gpu).to(torch.bfloat16)
+    aggregation.unprojection(f32, p, c, variant="gather", out_dtype=torch.bfloat16).backward(gb)
+    gref = cport.backward(gb.float().cpu().numpy(), feats, proj, coords, "softmax")
+    record_err("plane bwd, bf16 grad_out", _err(f32.grad.cpu().numpy(), gref), _bound(gref))
+    # the caller's quad-planar copy, explicit gather variant: no layout pass at all in the backward
+    L = _capi.lib()
+    vp = ctypes.c_void_p
+    stream = vp(torch.cuda.current_stream().cuda_stream)
+    f = torch.from_numpy(feats).to(gpu)
+    d = aggregation._make_desc(f, c, _capi.AGG["softmax"], torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["gather"])
+    quad = torch.empty(L.mvhmr_feature_layout_bytes(ctypes.byref(d), _capi.LAYOUT_QUAD), dtype=torch.uint8, device=gpu)
+    _capi.check(L.mvhmr_convert_features(ctypes.byref(d), vp(f.data_ptr()), _capi.LAYOUT_QUAD, vp(quad.data_ptr()), stream))
+    d.feat_layout = _capi.LAYOUT_QUAD
+    g = torch.empty_like(f)
+    nb = L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(nb, 1), dtype=torch.uint8, device=gpu)
+    got = torch.from_numpy(go).to(gpu)
+    _capi.check(L.mvhmr_unproject_backward(ctypes.byref(d), vp(got.data_ptr()), vp(quad.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(g.data_ptr()),
+                                           vp(ws.data_ptr()), nb, stream))
+    gref = cport.backward(go, feats, proj, coords, "softmax")
+    record_err("plane bwd from quad-planar features", _err(g.cpu().numpy(), gref), _bound(gref))
