@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(1024) k(float *out, unsigned long long *stamps
             if (OP == 0) a[i] = __builtin_fmaf(a[i], m, c);                          // 3 VGPR sources
             if (OP == 1) a[i] = __builtin_amdgcn_exp2f(a[i]);
             if (OP == 2) a[i] = __builtin_fmaf(a[i], 1.0001f, 0.0003f);              // literal operands
-            if (OP == 4) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a[i]), 0x104, 0xF, 0x5, false));
+            if (OP == 4) a[i] = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, a[i]), __builtin_bit_cast(int, a[(i + 8) & 15]), 0x104, 0xF, 0x5, false));
             if (OP == 5) a[i] = a[i] * m;
             if (OP == 6) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(hbits), "v"(m));
             if (OP == 7) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a[i]) : "v"(hbits), "v"(m));
@@ -74,6 +74,7 @@ int main()
         run<5>("v_mul_f32", t, 16);
         run<1>("v_exp_f32", t, 16);
         run<3>("v_pk_fma_f32", t, 8);
+        run<4>("v_mov_b32_dpp row_shl:4 (bank mask)", t, 16);
         run<6>("v_fma_mix_f32 (lo half)", t, 16);
         run<7>("v_fma_mix_f32 (hi half)", t, 16);
     }
