@@ -111,7 +111,7 @@ def cuboid_volume(batch, S, side=2500.0, seed=0):
     """aggregation.py:140-187 with theta = 0 (eval): origin-centred cuboid; the pivot is irrelevant at theta = 0."""
     g = np.stack(np.meshgrid(np.arange(S), np.arange(S), np.arange(S), indexing="ij"), -1).astype(np.float32)
     coords = (np.float32(-side / 2) + np.float32(side / (S - 1)) * g).astype(np.float32)
-    return np.ascontiguousarray(np.broadcast_to(coords, (batch,) + coords.shape))
+    return np.broadcast_to(coords, (batch,) + coords.shape).copy()
 
 
 def frustum_stats(P, coords, H, W):
