@@ -213,6 +213,18 @@ int mvhmr_conv1x1_wgrad(const float *grad_y, const float *x, float *grad_weight,
 int mvhmr_conv1x1_wgrad_supported(int32_t c_in, int32_t c_out, int32_t pixels);
 
 /*
+ * DLT triangulation of one 3-D point per sample from its V views: replaces triangulate_point_from_multiple_views_linear[_torch]
+ * (utils/multiview.py:112-168) where VolumeGenerator.forward calls it per sample with a device SVD and a .cpu() each
+ * (models/aggregation.py:174-177).  Homogeneous solution of A h = 0 (rows u P[2,:] - P[0,:], v P[2,:] - P[1,:]) as the smallest
+ * eigenvector of the normal matrix A^T A (the unit-norm least-squares solution, as the SVD gives it), float64 Jacobi rotations, one
+ * thread per sample, no host synchronisation.
+ *   proj    (B,V,3,4) fp32, device      points  (V,2) fp32 shared by the samples (points_per_sample = 0) or (B,V,2) (= 1), device
+ *   out     (B,3) fp32, device
+ */
+int mvhmr_triangulate_dlt(const float *proj, const float *points, float *out, int32_t batch, int32_t views,
+                          int32_t points_per_sample, void *hip_stream);
+
+/*
  * Caller-side helper of VolumeGenerator.forward (models/aggregation.py:138-187): fills
  * coords (B,S,S,S,3) fp32 with the cuboid grid `position + side/(S-1) * (i,j,k)` rotated by
  * rot[b] (3x3 row-major fp32, utils/volumetric.py:87-114) about center[b] (3 fp32):

@@ -593,6 +593,15 @@ int mvhmr_unproject_query_variant_cuboid(const mvhmr_unproject_desc *desc, const
     return host <= brick_count(p, g) / 8 ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
 }
 
+int mvhmr_triangulate_dlt(const float *proj, const float *points, float *out, int32_t batch, int32_t views, int32_t points_per_sample,
+                          void *hip_stream)
+{
+    if (!proj || !points || !out) return fail(MVHMR_ERR_INVALID_ARGUMENT, "null pointer");
+    if (batch < 1 || views < 2) return fail(MVHMR_ERR_INVALID_ARGUMENT, "batch must be >= 1 and views >= 2 (got %d, %d)", batch, views);
+    return launched(launch_triangulate_dlt(proj, points, out, batch, views, points_per_sample ? 1 : 0, static_cast<hipStream_t>(hip_stream)),
+                    "DLT triangulation");
+}
+
 int mvhmr_build_coord_volumes(float *coords, const float *rot, const float *center, int32_t batch, int32_t volume_size,
                               const double position[3], const double sides[3], void *hip_stream)
 {

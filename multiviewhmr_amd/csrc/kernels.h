@@ -97,6 +97,9 @@ hipError_t launch_conv1x1_quad(const float *x, const float *w, const float *bias
 // column-major quad-planar -> row-major quad-planar (planes = B * V * C / 4); gated like the brick kernels
 hipError_t launch_quad_transpose(const void *src, void *dst, int planes, int H, int W, const Gate &gate, hipStream_t s);
 
+// DLT triangulation of one point per sample (fp32 in / out, float64 inside); points (V,2) shared or (B,V,2) per sample
+hipError_t launch_triangulate_dlt(const float *proj, const float *points, float *out, int B, int V, int points_per_sample, hipStream_t s);
+
 hipError_t launch_build_coords(float *coords_out, const float *rot, const float *center, int B, int S,
                                const double pos[3], const double sides[3], hipStream_t s);
 

@@ -534,6 +534,63 @@ hipError_t launch_grad_cast(const float *srcT, void *dst, const Problem &p, hipS
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------ DLT triangulation
+// One point per sample from V views (utils/multiview.py:112-168, Hartley & Zisserman 12.2): the right singular vector of the smallest
+// singular value of A (2V x 4), rows u * P[2,:] - P[0,:] and v * P[2,:] - P[1,:] -- with inconsistent rays (the image centres of a
+// camera ring do not meet in one point) that is the minimiser of |A h| over UNIT h, so A must not be rescaled column-wise: the
+// constraint would change and with it the answer.  One thread per sample, float64 throughout: the smallest eigenvector of the 4 x 4
+// normal matrix A^T A by cyclic Jacobi rotations -- no SVD, no host round trip.  cond(A) is ~10^1..10^4 for pixel-scale projection
+// matrices, its square far inside float64 (agreement with numpy's float64 SVD: tests/test_unproject_gpu.py).
+__global__ void __launch_bounds__(64)
+k_triangulate_dlt(const float *__restrict__ proj, const float *__restrict__ points, float *__restrict__ out, int B, int V, int points_per_sample)
+{
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float *P = proj + (long long)b * V * 12;
+    const float *uv = points + (points_per_sample ? (long long)b * V * 2 : 0);
+    double M[4][4] = {{0}}, E[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    for (int v = 0; v < V; ++v)
+        for (int r = 0; r < 2; ++r) {
+            double a[4];
+            for (int k = 0; k < 4; ++k) a[k] = (double)uv[2 * v + r] * (double)P[v * 12 + 8 + k] - (double)P[v * 12 + 4 * r + k];
+            for (int i = 0; i < 4; ++i)
+                for (int j = 0; j < 4; ++j) M[i][j] += a[i] * a[j];
+        }
+    for (int sweep = 0; sweep < 12; ++sweep) {
+        double off = 0;
+        for (int i = 0; i < 4; ++i)
+            for (int j = i + 1; j < 4; ++j) off += M[i][j] * M[i][j];
+        if (off == 0.0) break;
+        for (int p = 0; p < 3; ++p)
+            for (int q = p + 1; q < 4; ++q) {
+                if (M[p][q] == 0.0) continue;
+                const double th = (M[q][q] - M[p][p]) / (2.0 * M[p][q]);
+                const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 4; ++k) {                                     // M <- M J
+                    const double mkp = M[k][p], mkq = M[k][q];
+                    M[k][p] = c * mkp - sn * mkq; M[k][q] = sn * mkp + c * mkq;
+                }
+                for (int k = 0; k < 4; ++k) {                                     // M <- J^T M, E <- E J
+                    const double mpk = M[p][k], mqk = M[q][k];
+                    M[p][k] = c * mpk - sn * mqk; M[q][k] = sn * mpk + c * mqk;
+                    const double ekp = E[k][p], ekq = E[k][q];
+                    E[k][p] = c * ekp - sn * ekq; E[k][q] = sn * ekp + c * ekq;
+                }
+            }
+    }
+    int m = 0;
+    for (int k = 1; k < 4; ++k) m = M[k][k] < M[m][m] ? k : m;
+    const double h0 = E[0][m], h1 = E[1][m], h2 = E[2][m], h3 = E[3][m];
+    out[3 * b + 0] = (float)(h0 / h3); out[3 * b + 1] = (float)(h1 / h3); out[3 * b + 2] = (float)(h2 / h3);
+}
+
+hipError_t launch_triangulate_dlt(const float *proj, const float *points, float *out, int B, int V, int points_per_sample, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_triangulate_dlt, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, proj, points, out, B, V, points_per_sample);
+    return hipGetLastError();
+}
+
 hipError_t launch_build_coords(float *coords, const float *rot, const float *center, int B, int S, const double pos[3],
                                const double sides[3], hipStream_t s)
 {

@@ -104,11 +104,24 @@ def triangulate_point_from_multiple_views_linear_torch(proj_matricies, points, c
 
 def triangulate_points_from_multiple_views_linear_batch(proj_matricies, points):
     """The same DLT for a whole batch at once: proj_matricies (B, V, 3, 4), points (V, 2) shared by the samples -> (B, 3),
-    on proj_matricies.device with no host synchronisation.  The caller (VolumeGenerator with use_triangulation, reference
+    on proj_matricies.device with no host synchronisation (HIP tensors: mvhmr_triangulate_dlt; CPU tensors -- tests without a GPU --
+    the batched float64 SVD below).  The caller (VolumeGenerator with use_triangulation, reference
     aggregation.py:174-177) triangulates the image centre of every sample; the reference does it sample by sample with a
     device SVD and a .cpu() each.  One batched float64 SVD of the (B, 2V, 4) system here; the right singular vector of the
     smallest singular value is the homogeneous point (its sign cancels in the dehomogenisation)."""
     B, V = proj_matricies.shape[:2]
+    if proj_matricies.is_cuda:
+        # the library's SVD-free kernel: one thread per sample, 4 x 4 normal matrix, float64 Jacobi rotations
+        import ctypes
+        from . import _capi
+        L = _capi.lib()
+        P32 = proj_matricies.detach().to(torch.float32).contiguous()
+        pts32 = points.detach().to(device=P32.device, dtype=torch.float32).contiguous()
+        out = torch.empty(B, 3, dtype=torch.float32, device=P32.device)
+        with torch.cuda.device(P32.device):
+            _capi.check(L.mvhmr_triangulate_dlt(ctypes.c_void_p(P32.data_ptr()), ctypes.c_void_p(pts32.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                B, V, 0, ctypes.c_void_p(torch.cuda.current_stream(P32.device).cuda_stream)))
+        return out
     P = proj_matricies.to(torch.float64)
     pts = points.to(device=P.device, dtype=torch.float64)
     A = P[:, :, 2:3].expand(B, V, 2, 4) * pts.view(1, V, 2, 1) - P[:, :, :2]

@@ -1205,3 +1205,31 @@ def test_plane_backward_storage_modes_and_quad_planar_features(gpu):
                                            vp(ws.data_ptr()), nb, stream))
     gref = cport.backward(go, feats, proj, coords, "softmax")
     record_err("plane bwd from quad-planar features", _err(g.cpu().numpy(), gref), _bound(gref))
+
+
+def test_dlt_triangulation_kernel_matches_the_svd(gpu):
+    """mvhmr_triangulate_dlt (SVD-free, on the device) against numpy's float64 SVD per sample (the reference's formulation,
+    utils/multiview.py:112-139) on ring rigs with 2, 4 and 8 views, exact and noisy image points"""
+    rng = np.random.default_rng(12)
+    for V in (2, 4, 8):
+        P = bench_projections(6, V)
+        X = rng.uniform(-800, 800, (6, 3))
+        hom = np.concatenate([X, np.ones((6, 1))], 1)
+        for noise in (0.0, 1.5):
+            got_all = []
+            for b in range(6):
+                r = np.einsum("vij,j->vi", P[b].astype(np.float64), hom[b])
+                uv = r[:, :2] / r[:, 2:3] + rng.normal(0, noise, (V, 2))
+                ref = multiview.triangulate_point_from_multiple_views_linear(P[b].astype(np.float64), uv)
+                got = multiview.triangulate_points_from_multiple_views_linear_batch(torch.from_numpy(P[b:b + 1]).to(gpu),
+                                                                                    torch.from_numpy(uv.astype(np.float32)).to(gpu))[0].cpu().numpy()
+                ref32 = multiview.triangulate_point_from_multiple_views_linear(P[b].astype(np.float64), uv.astype(np.float32).astype(np.float64))
+                got_all.append(np.abs(got - ref32).max())
+                if noise == 0.0:
+                    assert np.abs(ref - X[b]).max() < 1e-2
+            record_err("DLT kernel vs float64 SVD (mm), V=%d noise=%.1f" % (V, noise), float(max(got_all)), 2e-3)
+
+
+def bench_projections(B, V):
+    import bench
+    return bench.ring_projections(B, V, (96, 96), seed=5)
