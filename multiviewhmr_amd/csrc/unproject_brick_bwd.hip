@@ -23,7 +23,7 @@
 namespace mvhmr {
 
 // Timing-only ablations for scripts/exp (never defined in the product build): bit 0 no flush atomics, 1 plain stores instead of the
-// flush atomics, 2 no LDS adds
+// flush atomics, 2 no LDS adds, 3 no barriers in the quad loop (only the waits stay)
 #ifndef MVHMR_EXP_BWD
 #define MVHMR_EXP_BWD 0
 #endif
@@ -366,6 +366,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (q + 2 < nq) load_g(q + 2);
+            if constexpr (kExpB & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
             lds_barrier();                                                       // adds of quad q landed; max of quad q+1 published
             // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction
             float *gq = gk + (long long)q * HW * 4;
@@ -392,6 +393,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             if (tid < 4) sh->aux[(q & 1) * 4 + tid] = 0;                         // read by every wave before the barrier above
             // window q+2 and grad_out q+2 (requested before this quad's atomics) have landed; the atomics stay in flight
             wait_vmcnt(n_at);
+            if constexpr (kExpB & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
             lds_barrier();
         }
     } else {
