@@ -23,7 +23,7 @@
 namespace mvhmr {
 
 // Timing-only ablations for scripts/exp (never defined in the product build): bit 0 no flush atomics, 1 plain stores instead of the
-// flush atomics, 2 no LDS adds, 3 no barriers in the quad loop (only the waits stay)
+// flush atomics, 2 no LDS adds, 3 no barriers in the quad loop (only the waits stay), 4 / 5 waves 8-15 / odd waves start the quad loop ~3 us late
 #ifndef MVHMR_EXP_BWD
 #define MVHMR_EXP_BWD 0
 #endif
@@ -192,7 +192,12 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             const bool ok = (valid >> v) & 1u;
             const int s0 = slot0[v] + (ty[v] - wy0[v]) * ws[v] + (tx[v] - wx0[v]);
             a0[v] = ok ? kZeroBytes + s0 * 16 : 0;
-            ga[v] = ok ? kZeroSlots + s0 : 0;                                     // float index inside a gradient plane
+            // float index inside a gradient plane.  A lane whose sample is identically zero (weights 0: it adds integer zeros) is
+            // parked on its own pair of words of the always-zero head (rows 0 / 1 of its "taps" then lie <= 126 + 127 words further:
+            // still zero head or real slots, where + 0 changes nothing) -- parked on ONE word the lanes would serialise (same-address
+            // LDS atomics: 2 cycles per lane), and masking them off instead costs an exec mask + branch per (channel, view) for nothing:
+            // an exec-masked ds_add_u32 is as expensive as a full one (scripts/microbench_ldsmask.hip)
+            ga[v] = ok ? kZeroSlots + s0 : 2 * lane;
             ws16[v] = ws[v] * 16;
         }
         // ---- chunks of this wave (64 consecutive window slots of one view): DMA source + flush destination
@@ -309,6 +314,10 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         if (nq > 1) load_g(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // window 1 has landed
         lds_barrier();
+        if constexpr (kExpB & 48) {
+            const bool late = (kExpB & 16) ? wave >= NW / 2 : (wave & 1);
+            if (late) for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(1);   // ~64 cycles each
+        }
 #pragma nounroll
         for (int q = 0; q < nq; ++q) {
             // LDS float atomics run at ~190 cycles per wave instruction on gfx950, integer ones at ~4-6, so the window is
@@ -349,9 +358,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                     int r0 = ga[v] * 4;
                     asm volatile("" : "+v"(r0));
                     const int r1 = r0 + ws[v] * 4;
-                    // lanes whose sample is identically zero add nothing: parked on the zero slot they would all hit ONE
-                    // address, and same-address LDS atomics serialise (2 cycles per lane)
-                    if (((valid >> v) & 1u) && !(kExpB & 4)) {
+                    if (!(kExpB & 4)) {
                         const float d = ds[i][v] * scale[i];
                         int *p0 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r0);
                         int *p1 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r1);
