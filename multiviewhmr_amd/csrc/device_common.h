@@ -176,9 +176,17 @@ __device__ __forceinline__ void aggregate_grad(const float (&s)[V], float g, flo
 #pragma unroll
         for (int v = 0; v < V; ++v) ds[v] = v == am ? g : 0.f;
     } else {
+        // the same max as the forward's aggregate<> (no canonicalising v_max x,x in front of every operand, v_max3 where three
+        // operands are at hand): the value is identical
         float m = s[0];
+        if constexpr (V >= 3) {
+            m = vmax3(s[0], s[1], s[2]);
 #pragma unroll
-        for (int v = 1; v < V; ++v) m = fmaxf(m, s[v]);
+            for (int v = 3; v + 1 < V; v += 2) m = vmax3(m, s[v], s[v + 1]);
+            if constexpr ((V - 3) % 2 == 1) m = vmax(m, s[V - 1]);
+        } else if constexpr (V == 2) {
+            m = vmax(s[0], s[1]);
+        }
         const float nm = -m * 1.4426950408889634f;
         float e[V], den = 0.f, num = 0.f;
 #pragma unroll
