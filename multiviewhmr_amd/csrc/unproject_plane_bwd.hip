@@ -139,14 +139,20 @@ k_bwd_plane(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     // nothing of the 31 bits is given away to a power-of-two rounding of the bound or of the multiplicity
     const int cm = uniform(cmax[b * VT + v_own]);
     const float range = METHOD == AGG_SOFTMAX ? __builtin_bit_cast(float, uniform(sh->fpos)) + __builtin_bit_cast(float, uniform(sh->fneg)) : 0.f;
-    float scale[4], inv_scale[4];                                                 // 0: this channel's grad_out is all zero (or the bound overflows)
+    float scale[4], inv_scale[4];                                                 // 0: every finite grad_out of this channel is zero
+    bool over[4];                                                                 // the bound itself overflows fp32: nothing can be scaled
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float full = (float)cm * (__builtin_bit_cast(float, uniform(sh->gmax[i])) * (1.f + range) * 1.00390625f);
         const bool ok = full > 0.f && full < 3.0e38f;
+        over[i] = !(full < 3.0e38f);                                              // (inf included): non-zero contributions become NaN pixels
         scale[i] = uniform(ok ? __fdiv_rn(2139095040.f, full) : 0.f);            // wave-uniform: scalar registers
         inv_scale[i] = uniform(ok ? __fdiv_rn(full, 2139095040.f) : 0.f);
     }
+    // a contribution fixed point cannot carry: Inf / NaN, or anything non-zero under an overflowing bound
+    auto uncarried = [&](float dv, int i) __attribute__((always_inline)) {
+        return (__builtin_bit_cast(int, dv) & 0x7fffffff) >= 0x7f800000 || (over[i] && dv != 0.f);
+    };
     bool any_poison = false;
 
     // table entries and grad_out of the NEXT chunk are requested before this chunk's arithmetic: the taps' addresses come from the
@@ -239,10 +245,10 @@ k_bwd_plane(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         if (taps) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (scale[i] == 0.f) continue;                                    // block-uniform: this channel's grad_out is all zero
-                int *pl = planes + i * cells;
-                const bool nf = (__builtin_bit_cast(int, d[i]) & 0x7fffffff) >= 0x7f800000;
+                const bool nf = uncarried(d[i], i);
                 nf_any |= nf;
+                if (scale[i] == 0.f) continue;                                    // block-uniform: nothing finite to add in this channel
+                int *pl = planes + i * cells;
                 const float dsc = nf ? 0.f : d[i] * scale[i];
                 lds_add(pl + a00, round_int(dsc * wo.x));
                 lds_add(pl + a01, round_int(dsc * wo.y));
@@ -253,7 +259,7 @@ k_bwd_plane(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         if (__builtin_expect(__builtin_amdgcn_ballot_w64(nf_any) != 0, 0)) {     // rare: exactly the pixels a float scatter would poison
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                if (!taps || (__builtin_bit_cast(int, d[i]) & 0x7fffffff) < 0x7f800000) continue;
+                if (!taps || !uncarried(d[i], i)) continue;
                 unsigned *pm = poison + i * mask_words;
                 if (wo.x != 0.f) atomicOr(pm + (a00 >> 5), 1u << (a00 & 31));
                 if (wo.y != 0.f) atomicOr(pm + (a01 >> 5), 1u << (a01 & 31));

@@ -1233,3 +1233,29 @@ def test_dlt_triangulation_kernel_matches_the_svd(gpu):
 def bench_projections(B, V):
     import bench
     return bench.ring_projections(B, V, (96, 96), seed=5)
+
+
+def test_plane_backward_poisons_when_a_channel_has_only_non_finite_gradients(gpu):
+    """A channel whose grad_out is NaN wherever it is not zero has no finite magnitude to scale by: its NaN contributions must still
+    reach exactly their pixels (and an overflowing bound turns non-zero contributions into NaN pixels instead of dropping them)"""
+    shape = dict(B=1, V=4, C=4, H=24, W=24, vol=(8, 8, 8))
+    feats, proj, coords = _ring_problem(seed=41, **shape)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    go = np.zeros((1, 4, 8, 8, 8), np.float32)
+    go[0, 1, 3, 4, 5] = np.nan                                                  # channel 1: one NaN, everything else zero
+    go[0, 2] = np.random.default_rng(1).standard_normal((8, 8, 8)).astype(np.float32)
+    grads = {}
+    for layout in ("planar", "channels_last"):                                   # plane kernel / per-tap scatter
+        f = torch.from_numpy(feats).to(gpu)
+        f = (_channels_last(f) if layout == "channels_last" else f).requires_grad_(True)
+        aggregation.unprojection(f, p, c, variant="gather").backward(torch.from_numpy(go).to(gpu))
+        grads[layout] = f.grad
+    a, b = grads["planar"], grads["channels_last"]
+    assert torch.equal(torch.isnan(a), torch.isnan(b)) and bool(torch.isnan(a[0, :, 1]).any())      # the same pixels, and there are some
+    assert not bool(torch.isnan(a[0, :, 0]).any()) and not bool(torch.isnan(a[0, :, 2]).any())
+    record_err("plane vs scatter bwd next to a NaN channel", float((a[0, :, 2] - b[0, :, 2]).abs().max()), 1e-5)
+    huge = np.zeros_like(go)
+    huge[0, 0, 2, 2, 2] = 3e38                                                   # times the tap multiplicity: the bound overflows fp32
+    f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    aggregation.unprojection(f, p, c, variant="gather").backward(torch.from_numpy(huge).to(gpu))
+    assert not bool(torch.isfinite(f.grad[0, :, 0]).all())                       # visible, not silently zero
