@@ -127,7 +127,18 @@ def _autograd_backward(ctx, grad_out):
     return g, None, None, None, None, None
 
 
+def _op_defined(name):
+    """True when mvhmr::<name> already exists (the module imported twice under two names, importlib.reload): define() would raise"""
+    try:
+        getattr(torch.ops.mvhmr, name)
+        return True
+    except (AttributeError, RuntimeError):
+        return False
+
+
 def _register_ops():
+    if _op_defined("unprojection"):
+        return
     sig = "(Tensor features, Tensor proj, Tensor coords, int method, int out_dtype, int variant) -> Tensor"
     torch.library.define("mvhmr::unprojection", sig)
     torch.library.define("mvhmr::unprojection_backward", "(Tensor grad_out, " + sig[1:])
@@ -236,6 +247,8 @@ def _opc_autograd(ctx, grad_out):
 
 
 def _register_cuboid_ops():
+    if _op_defined("unprojection_cuboid"):
+        return
     sig = "(Tensor features, Tensor proj, Tensor rot, Tensor center, float[] position, float[] sides, int[] vol, int method, int out_dtype, int variant) -> Tensor"
     torch.library.define("mvhmr::unprojection_cuboid", sig)
     torch.library.define("mvhmr::unprojection_cuboid_backward", "(Tensor grad_out, " + sig[1:])
