@@ -5,7 +5,7 @@
 // (channel quad, view group): only the windows of VG = 4 views are resident at a time, so a 4 x 8 x 32 brick fits a 2-deep ring
 // (group windows: mean 2 500, max 4 000 slots at the configs[3] geometry; 29 % fewer window pixels per voxel than 4 x 4 x 32), and a
 // lane keeps one tap set and the 32 samples of its voxel: 128 VGPRs, four waves per SIMD.  The samples of both groups meet in
-// registers and go through the same aggregate<METHOD, 8> as in k_fwd_brick: identical results.
+// registers and go through the same aggregate2<METHOD, 8> as in k_fwd_brick: identical results.
 // Same lane map, column-major windows, stride-4 DPP transpose and stores as k_fwd_brick (brick_fwd_kernel.h).
 #pragma once
 #include "brick_fwd_kernel.h"
@@ -240,7 +240,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
             }
             float res[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) res[i] = aggregate<METHOD, VT>(s[i]);
+            for (int i = 0; i < 4; i += 2) aggregate2<METHOD, VT>(s[i], s[i + 1], res[i], res[i + 1]);
             store_quad(q, res);
         }
     } else {

@@ -95,6 +95,18 @@ __device__ __forceinline__ float fwd_aggregate(const float (&s)[VT])
     }
 }
 
+// aggregate2<> behind the timing-only ablations
+template <int METHOD, int VT>
+__device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const float (&sb)[VT], float &ra, float &rb)
+{
+    if constexpr (kExp & (16 | 128)) {
+        ra = fwd_aggregate<METHOD, VT>(sa);
+        rb = fwd_aggregate<METHOD, VT>(sb);
+    } else {
+        aggregate2<METHOD, VT>(sa, sb, ra, rb);
+    }
+}
+
 template <int VT>
 struct FwdShared {
     int bbox[VT][4];               // xmin, ymin, xmax, ymax of the nw taps (valid voxels only)
@@ -336,14 +348,12 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 read_view(q, u, 0, 0);
                 if constexpr (VT > 1) read_view(q, u, 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                res[0] = fwd_aggregate<METHOD, VT>(prev[0]);
-                res[1] = fwd_aggregate<METHOD, VT>(prev[1]);
+                fwd_aggregate2<METHOD, VT>(prev[0], prev[1], res[0], res[1]);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int v = 0; v < VT; ++v) {
                     if (v == (VT + 1) / 2) {
-                        res[2] = fwd_aggregate<METHOD, VT>(prev[2]);
-                        res[3] = fwd_aggregate<METHOD, VT>(prev[3]);
+                        fwd_aggregate2<METHOD, VT>(prev[2], prev[3], res[2], res[3]);
                         if (st) store_quad(u > 0 ? q : q - 1, u > 0 ? u - 1 : NVOX - 1, res);
                         __builtin_amdgcn_sched_barrier(0);
                     }
@@ -370,7 +380,10 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // the last job: (nq - 1, NVOX - 1)
         const bool last_in_sp = ((NVOX & 1) ? nq - 1 : NVOX - 1) & 1;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) res[c] = last_in_sp ? fwd_aggregate<METHOD, VT>(sp[c]) : fwd_aggregate<METHOD, VT>(sq[c]);
+        for (int c = 0; c < 4; c += 2) {
+            if (last_in_sp) fwd_aggregate2<METHOD, VT>(sp[c], sp[c + 1], res[c], res[c + 1]);
+            else fwd_aggregate2<METHOD, VT>(sq[c], sq[c + 1], res[c], res[c + 1]);
+        }
         store_quad(nq - 1, NVOX - 1, res);
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (clamped taps, zero weights outside)

@@ -144,17 +144,56 @@ __device__ __forceinline__ float aggregate(const float (&s)[V])
         } else if constexpr (V == 2) {
             m = vmax(s[0], s[1]);
         }
-        // e_v = exp(s_v - m) as exp2((s_v - m) * log2e): one fma + v_exp_f32 per view
-        const float nm = -m * 1.4426950408889634f;
-        const float e0 = __builtin_amdgcn_exp2f(fmaf(s[0], 1.4426950408889634f, nm));
+        // e_v = exp(s_v - m) as exp2((s_v - m) * log2e).  The difference is taken FIRST (exact for the maximum, a few ulps of the
+        // difference otherwise): folding it into fma(s_v, log2e, -m * log2e) saves one instruction per view but leaves the
+        // rounding of m * log2e in the exponent -- |m| * 2^-24, i.e. weights off by 1e-7 |m| and garbage beyond |m| ~ 1e9
+        const float e0 = __builtin_amdgcn_exp2f((s[0] - m) * 1.4426950408889634f);
         float den = e0, num = e0 * s[0];
 #pragma unroll
         for (int v = 1; v < V; ++v) {
-            const float e = __builtin_amdgcn_exp2f(fmaf(s[v], 1.4426950408889634f, nm));
+            const float e = __builtin_amdgcn_exp2f((s[v] - m) * 1.4426950408889634f);
             den += e;
             num = fmaf(e, s[v], num);
         }
         return num * __builtin_amdgcn_rcpf(den);   // den >= 1 (the max term contributes exp(0))
+    }
+}
+
+// Two channels at once for the brick forward kernels (VALU-bound: scripts/loop_histogram.py).  Softmax with the exponentials taken
+// relative to VIEW 0 instead of the maximum:
+//   out = (s_0 + sum_{v>0} e_v s_v) / (1 + sum_{v>0} e_v),   e_v = exp(s_v - s_0)
+// V - 1 v_exp_f32 instead of V and no v_max3 / v_max (3.5 ns and 2.0 ns per wave instruction against 1.1 for an fma:
+// scripts/microbench_ops.hip).  Algebraically the same weights; what the max form buys is range: here e_v overflows once
+// s_v - s_0 > 88.7.  Every way that can go wrong ends non-finite somewhere: an overflowed e_v makes den = Inf; finite e_v whose sum
+// overflows make den = Inf; an overflowed e_v s_v makes num and the quotient Inf or NaN; non-finite samples make everything NaN.
+// One class test on  den_a * den_b + (r_a + r_b)  therefore catches every such case of either channel (Inf - Inf reads NaN: still
+// caught; den_a * den_b >= 2^128 with both quotients fine is a false alarm, only slow), and the wave redoes both channels in the
+// max form -- a wave-uniform branch.  Underflow is harmless: e_v -> 0 is the limit of the weight.
+template <int METHOD, int V>
+__device__ __forceinline__ void aggregate2(const float (&sa)[V], const float (&sb)[V], float &ra, float &rb)
+{
+    if constexpr (METHOD == AGG_SOFTMAX && V > 1) {
+        auto one = [](const float (&s)[V], float &den) __attribute__((always_inline)) {
+            float num = s[0];
+            den = 1.f;
+#pragma unroll
+            for (int v = 1; v < V; ++v) {
+                const float e = __builtin_amdgcn_exp2f((s[v] - s[0]) * 1.4426950408889634f);
+                den += e;
+                num = fmaf(e, s[v], num);
+            }
+            return num * __builtin_amdgcn_rcpf(den);
+        };
+        float da, db;
+        ra = one(sa, da);
+        rb = one(sb, db);
+        if (__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(fmaf(da, db, ra + rb)) < __builtin_inff())) != 0) {
+            ra = aggregate<METHOD, V>(sa);
+            rb = aggregate<METHOD, V>(sb);
+        }
+    } else {
+        ra = aggregate<METHOD, V>(sa);
+        rb = aggregate<METHOD, V>(sb);
     }
 }
 
@@ -187,11 +226,10 @@ __device__ __forceinline__ void aggregate_grad(const float (&s)[V], float g, flo
         } else if constexpr (V == 2) {
             m = vmax(s[0], s[1]);
         }
-        const float nm = -m * 1.4426950408889634f;
         float e[V], den = 0.f, num = 0.f;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            e[v] = __builtin_amdgcn_exp2f(fmaf(s[v], 1.4426950408889634f, nm));
+            e[v] = __builtin_amdgcn_exp2f((s[v] - m) * 1.4426950408889634f);       // difference first, as in aggregate<>
             den += e[v];
             num = fmaf(e[v], s[v], num);
         }

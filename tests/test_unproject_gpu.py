@@ -160,7 +160,42 @@ def test_brick_variant_vs_oracle(shape, mode, gpu):
     assert torch.equal(out, aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick"))   # deterministic
     gat = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="gather")
     record_err("brick vs gather fwd %s V%d C%d %dx%d vol%s" % (mode, shape["V"], shape["C"], shape["H"], shape["W"], shape["vol"]),
-               float((out - gat).abs().max()), 2e-6)         # same arithmetic, two kernels
+               float((out - gat).abs().max()), 4e-6)         # same samples; the softmax in two algebraically equal forms
+
+
+@pytest.mark.parametrize("views", (2, 4, 8))
+def test_brick_softmax_over_the_whole_float_range(views, gpu):
+    """The brick forward takes its softmax exponentials relative to view 0 (one v_exp_f32 and the max fewer per channel) and
+    falls back to the max form, per wave, when that overflows (s_v - s_0 > 88.7) or meets a non-finite sample
+    (brick_fwd_kernel.h, fwd_aggregate2).  Samples spread over +-300, +-3e4 and +-1e30 take both branches; the answer stays the
+    oracle's -- relative bound, the values are large -- and never turns non-finite where the reference is finite."""
+    feats, proj, coords = _ring_problem(B=1, V=views, C=8, H=24, W=24, vol=(8, 8, 32), seed=77)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    for scale in (100.0, 1e4, 1e30):
+        f = np.ascontiguousarray(feats * np.float32(scale))
+        f[0, :, 1] = feats[0, :, 1]                                               # one channel of each quad stays O(1): mixed waves
+        f[0, 0, 2] -= np.float32(0.9 * scale)                                     # view 0 far below the others: e_v overflows
+        f[0, 0, 3] += np.float32(0.9 * scale)                                     # view 0 far above: every e_v underflows to 0
+        with np.errstate(all="ignore"):
+            ref = cport.forward(f, proj, coords, "softmax")
+        assert np.isfinite(ref).all()
+        out = aggregation.unprojection(torch.from_numpy(f).to(gpu), p, c, aggregation_method="softmax", variant="brick").cpu().numpy()
+        assert np.isfinite(out).all()
+        big = [0, 2, 3, 4, 5, 6, 7]                                               # the O(1) channel keeps the absolute bar
+        record_err("brick softmax range V%d x%g, O(1) channel" % (views, scale), _err(out[0, 1], ref[0, 1]), TOL)
+        record_err("brick softmax range V%d x%g, relative to max |ref|" % (views, scale),
+                   _err(out[0, big], ref[0, big]) / float(np.abs(ref[0, big]).max()), 8e-6)
+    fn = feats.copy()
+    fn[0, 0, 5, 10:14, 10:14] = np.nan                                            # NaN samples in view 0, Inf in view 1
+    fn[0, 1, 6, 8:12, 8:12] = np.inf
+    with np.errstate(all="ignore"):
+        ref = cport.forward(fn, proj, coords, "softmax")
+    out = aggregation.unprojection(torch.from_numpy(fn).to(gpu), p, c, aggregation_method="softmax", variant="brick").cpu().numpy()
+    gat = aggregation.unprojection(torch.from_numpy(fn).to(gpu), p, c, aggregation_method="softmax", variant="gather").cpu().numpy()
+    assert np.array_equal(np.isfinite(out), np.isfinite(gat)) and (~np.isfinite(out)).any()      # the max form's pixels exactly
+    fin = np.isfinite(ref) & np.isfinite(out)
+    assert fin[0, [0, 1, 2, 3, 4, 7]].all()
+    record_err("brick softmax non-finite samples V%d, finite part" % views, _err(out[fin], ref[fin]), TOL)
 
 
 @pytest.mark.parametrize("shape", [
