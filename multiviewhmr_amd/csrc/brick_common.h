@@ -158,4 +158,38 @@ __device__ __forceinline__ int wave_max_dpp(int x)
     return ab > cd ? ab : cd;
 }
 
+// max over the wave, left in the lanes of the last 16-lane row (lane 63 among them): six fused v_max_i32_dpp -- four inside the rows
+// (quad_perm, mirrors), row_bcast:15 into rows 1 / 3, row_bcast:31 into rows 2 / 3.  DPP moves and integer max both issue at half the
+// fma rate on gfx950 (scripts/microbench_ops.hip), so the fused form halves the cost of the mov + max pairs hipcc makes of
+// update_dpp; s_nop 1 = the two wait states a DPP read needs after a VALU write of its source.  x >= 0.
+__device__ __forceinline__ int wave_max_to_last_row(int x)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+                 "v_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+                 : "+v"(x));
+    return x;
+}
+
+// ds_max_i32 of lane 63's value into one LDS word (byte address, wave-uniform).  Written with an explicit exec mask: behind
+// `if (lane == 63) atomicMax(...)` hipcc's atomic optimiser builds its own wave reduction (v_mbcnt, v_readfirstlane, compares).
+// Completion: the next s_waitcnt lgkmcnt(0) (lds_barrier).
+__device__ __forceinline__ void lds_max_from_lane63(unsigned lds_addr, int v)
+{
+    unsigned long long save;
+    unsigned a;
+    asm volatile("v_mov_b32 %1, %3\n\t"
+                 "s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %4\n\t"
+                 "ds_max_i32 %1, %2\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save), "=&v"(a)
+                 : "v"(v), "s"(lds_addr), "s"(0x8000000000000000ull)
+                 : "memory");
+}
+
 }  // namespace mvhmr

@@ -28,6 +28,14 @@ namespace mvhmr {
 #define MVHMR_EXP_BWD 0
 #endif
 constexpr int kExpB = MVHMR_EXP_BWD;
+typedef int int4v __attribute__((ext_vector_type(4)));                 // a buffer descriptor as four SGPRs (inline asm operand)
+// bit 6: phase timers of the quad loop (s_memtime, summed over all waves): mvhmr_exp_timers_read() -- experiment builds only
+#if MVHMR_EXP_BWD & 64
+__device__ unsigned long long g_exp_timers[8];
+#define EXP_T(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define EXP_T(i) do { } while (0)
+#endif
 
 // LDS: [ feature buffer 0 | feature buffer 1 | 4 gradient planes | BrickShared ]
 //   feature buffer = kZeroBytes of zeros + cap 16-B slots (as in the forward)
@@ -186,22 +194,22 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         for (int i = tid; i < 4 * plane_floats; i += NT) iplanes[i] = 0;
         if (tid < 9) sh->aux[tid] = 0;
 
-        int a0[VT], ws16[VT], ga[VT];
+        int a0[VT], ws16[VT], ga4[VT];
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             const bool ok = (valid >> v) & 1u;
             const int s0 = slot0[v] + (ty[v] - wy0[v]) * ws[v] + (tx[v] - wx0[v]);
             a0[v] = ok ? kZeroBytes + s0 * 16 : 0;
-            // float index inside a gradient plane.  A lane whose sample is identically zero (weights 0: it adds integer zeros) is
+            // byte offset inside a gradient plane.  A lane whose sample is identically zero (weights 0: it adds integer zeros) is
             // parked on its own pair of words of the always-zero head (rows 0 / 1 of its "taps" then lie <= 126 + 127 words further:
             // still zero head or real slots, where + 0 changes nothing) -- parked on ONE word the lanes would serialise (same-address
             // LDS atomics: 2 cycles per lane), and masking them off instead costs an exec mask + branch per (channel, view) for nothing:
             // an exec-masked ds_add_u32 is as expensive as a full one (scripts/microbench_ldsmask.hip)
-            ga[v] = ok ? kZeroSlots + s0 : 2 * lane;
+            ga4[v] = (ok ? kZeroSlots + s0 : 2 * lane) * 4;                        // as a byte offset: no shift per use
             ws16[v] = ws[v] * 16;
         }
         // ---- chunks of this wave (64 consecutive window slots of one view): DMA source + flush destination
-        unsigned g_off[MC];                                              // bit 0: the lane's slot is a real window pixel inside the image
+        unsigned g_off[MC];                                              // bit 31: the lane's slot is NOT a window pixel inside the image
         int l_dst[MC], c_slot[MC];
 #pragma unroll
         for (int r = 0; r < MC; ++r) {
@@ -219,7 +227,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 const int gx = ox + px, gy = oy + py;
                 const unsigned live = (px < bw && py < bh && gx >= 0 && gx < W && gy >= 0 && gy < H) ? 1u : 0u;
                 const int cx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx), cy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-                g_off[r] = ((unsigned)((v * nq) * HW + cy * W + cx) * 16u) | live;
+                g_off[r] = ((unsigned)((v * nq) * HW + cy * W + cx) * 16u) | (live ? 0u : 0x80000000u);
                 l_dst[r] = kZeroBytes + (s0 + (jj << 6)) * 16;
                 c_slot[r] = kZeroSlots + s0 + (jj << 6);
             }
@@ -230,7 +238,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             const int boff = (q & (NBUF - 1)) * buf_bytes;
 #pragma unroll
             for (int r = 0; r < MC; ++r)
-                if (l_dst[r] >= 0) glds16(src, g_off[r] & ~15u, lds_base + (unsigned)uniform(l_dst[r] + boff));
+                if (l_dst[r] >= 0) glds16(src, g_off[r] & 0x7fffffffu, lds_base + (unsigned)uniform(l_dst[r] + boff));
         };
 
         // grad_out of this voxel's 4 channels (128-B runs per channel across the wave), one quad ahead
@@ -252,7 +260,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         lds_barrier();                                                           // planes are zero
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
-            int *p = iplanes + ga[v];
+            int *p = iplanes + (ga4[v] >> 2);
             if ((valid >> v) & 1u) { lds_add(p, 1); lds_add(p + 1, 1); lds_add(p + ws[v], 1); lds_add(p + ws[v] + 1, 1); }
         }
         lds_barrier();
@@ -279,6 +287,11 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         //   barrier             planes zero, window q+2 landed (counted wait: the flush atomics stay in flight)
         // Requests go out BEFORE the flush: a CU's vector-memory pipe is in order and a flush's ~160 atomic instructions take
         // microseconds to drain -- loads queued behind them would stall the next quad.
+        const unsigned aux_base = (unsigned)(size_t)(lds_void_t *)sh->aux;
+        const unsigned ch4 = 4u * (lane & 3);                                    // this lane's channel in the flush
+        const unsigned long long gk_bits = (unsigned long long)(size_t)gk;
+        const int4v dgk = {uniform((int)(unsigned)gk_bits), uniform((int)((unsigned)(gk_bits >> 32) & 0xffffu)), (int)((unsigned)VT * nq * HW * 16u), 0x00020000};
+        const __amdgpu_buffer_rsrc_t rgk = __builtin_amdgcn_make_buffer_rsrc(gk, 0, (int)((unsigned)VT * nq * HW * 16u), 0x00020000);   // this sample's accumulator
         float ds[4][VT], s[4][VT];
         auto resample = [&](int q) {                                             // samples of quad q from its window buffer
             const int boff = (q & (NBUF - 1)) * buf_bytes;
@@ -301,10 +314,17 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // max |ds| on the BITS (sign cleared): non-negative floats order as ints, and Inf / NaN (>= 0x7f800000) sort above
             // every finite value instead of being dropped as fmaxf drops a NaN -- a non-finite gradient must stay visible
             int big = 0;
+            if constexpr (VT == 4) {
+                const int b0 = __builtin_bit_cast(int, ds[i][0]) & 0x7fffffff, b1 = __builtin_bit_cast(int, ds[i][1]) & 0x7fffffff;
+                const int b2 = __builtin_bit_cast(int, ds[i][2]) & 0x7fffffff, b3 = __builtin_bit_cast(int, ds[i][3]) & 0x7fffffff;
+                asm("v_max3_i32 %0, %1, %2, %3" : "=v"(big) : "v"(b0), "v"(b1), "v"(b2));
+                big = b3 > big ? b3 : big;
+            } else {
 #pragma unroll
-            for (int v = 0; v < VT; ++v) { const int a = __builtin_bit_cast(int, ds[i][v]) & 0x7fffffff; big = a > big ? a : big; }
-            const int bb = wave_max_dpp(big);
-            if (lane == 0) atomicMax(&sh->aux[(q & 1) * 4 + i], bb);                // one scale per channel of the quad
+                for (int v = 0; v < VT; ++v) { const int a = __builtin_bit_cast(int, ds[i][v]) & 0x7fffffff; big = a > big ? a : big; }
+            }
+            // one scale per channel of the quad: wave max -> lane 63 -> ds_max into the block's word
+            lds_max_from_lane63(aux_base + (unsigned)(((q & 1) * 4 + i) * 4), wave_max_to_last_row(big));
         };
         if (NBUF == 2 && nq > 1) dma(1);
         resample(0);
@@ -318,6 +338,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             const bool late = (kExpB & 16) ? wave >= NW / 2 : (wave & 1);
             if (late) for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(1);   // ~64 cycles each
         }
+#if MVHMR_EXP_BWD & 64
+        unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#endif
 #pragma nounroll
         for (int q = 0; q < nq; ++q) {
             // LDS float atomics run at ~190 cycles per wave instruction on gfx950, integer ones at ~4-6, so the window is
@@ -328,7 +351,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // The LDS pipe is in order: the window reads of quad q+1 go ahead of this quad's 64 adds per lane, whose
             // service time then hides under the Jacobian of quad q+1 (VALU only).
             if (q + 1 < nq) resample(q + 1);
+            EXP_T(0);                                                            // resample issued (+ loop top)
             float scale[4], inv_scale[4];
+            bool poisoned = false;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int bbits = uniform(sh->aux[(q & 1) * 4 + i]);
@@ -340,7 +365,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 // a non-finite |ds| somewhere in the brick (overflowed or NaN grad_out): fixed point cannot carry it.  The channel
                 // adds nothing (scale 0) and the flush writes NaN to every live pixel of the brick's windows instead -- a superset
                 // of the pixels the reference's float scatter would poison, so that isfinite() checks downstream still trip.
-                if (bbits >= 0x7f800000) { scale[i] = 0.f; inv_scale[i] = __builtin_nanf(""); }
+                if (bbits >= 0x7f800000) { scale[i] = 0.f; inv_scale[i] = __builtin_nanf(""); poisoned = true; }
             }
             if (q + 2 < nq) {
                 if (NBUF == 1) lds_barrier();                                    // single buffer: every wave has sampled window q+1
@@ -355,7 +380,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 for (int v = 0; v < VT; ++v) {
                     // two address registers (tap row 0 / row 1); planes and the +1 column are immediate offsets.
                     // Opaque to the optimiser: hoisted out of the loop they become pinned registers and the kernel spills
-                    int r0 = ga[v] * 4;
+                    int r0 = ga4[v];
                     asm volatile("" : "+v"(r0));
                     const int r1 = r0 + ws[v] * 4;
                     if (!(kExpB & 4)) {
@@ -373,36 +398,77 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (q + 2 < nq) load_g(q + 2);
+            EXP_T(1);                                                            // scales, DMA request, adds + Jacobian issued
             if constexpr (kExpB & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
             lds_barrier();                                                       // adds of quad q landed; max of quad q+1 published
-            // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction
-            float *gq = gk + (long long)q * HW * 4;
-            int n_at = 0;                                                        // atomic instructions this wave issues for this quad
+            EXP_T(2);                                                            // barrier 1
+            // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction.
+            // A slot that is not a live pixel (padding, outside the image) carries bit 31 in its offset: beyond the buffer's
+            // num_records (< 2^31, brick_bwd_supported), so the hardware drops that lane's atomic.  Lanes whose sum is exactly zero
+            // are masked off with v_cmpx (zero-lane atomics cost 0.35 ms of L2 atomic time at the north star) and an instruction
+            // without lanes is skipped; the wave counts what it issued (n_dyn) for the vmcnt wait below.  A quad with a poisoned
+            // channel (inv_ch is NaN: 0 * NaN = NaN) adds every lane instead: NaN goes to every LIVE pixel.
+            // The first form of this flush tested `add` in C++: a compare, a select, a ballot and two branches per instruction,
+            // serialised behind the LDS read they test, plus the 64-bit address arithmetic of a global_atomic -- 7 slow + 3 fast
+            // VALU instructions per element against 2 + 2 here (scripts/loop_histogram.py).
+            const int q_off = q * HW * 16;                                       // wave-uniform byte offset of the quad (soffset)
             const float inv_ch = (lane & 2) ? ((lane & 1) ? inv_scale[3] : inv_scale[2]) : ((lane & 1) ? inv_scale[1] : inv_scale[0]);
+            int n_dyn = 0;                                                       // atomic instructions this wave issues for this quad
+            auto flush = [&](auto masked_tag) __attribute__((always_inline)) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
-            for (int r = 0; r < MC; ++r) {
-                if (l_dst[r] < 0) continue;
+                for (int r = 0; r < MC; ++r) {
+                    if (l_dst[r] < 0) continue;
+                    int *pl = iplanes + (lane & 3) * plane_floats + c_slot[r] + (lane >> 2);
+                    unsigned off[4];
+                    int iv[4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const int srcl = 16 * jj + (lane >> 2), ch = lane & 3;
-                    const unsigned off = (unsigned)__shfl((int)g_off[r], srcl);    // byte offset of that slot's pixel (view base included) | live
-                    int *pl = iplanes + ch * plane_floats + c_slot[r] + srcl;
-                    const int iv = *pl;
-                    *pl = 0;                                                      // ready for the next quad
-                    const bool add = (off & 1u) && (iv != 0 || inv_ch != inv_ch);   // poisoned channel (inv_ch is NaN): every live pixel
-                    if (__builtin_amdgcn_ballot_w64(add) != 0 && !(kExpB & 1)) {    // wave-uniform: the instruction is issued or not
-                        if constexpr (kExpB & 2) { if (add) __builtin_nontemporal_store((float)iv * inv_ch, gq + (off >> 2) + ch); }
-                        else if (add) atomicAdd(gq + (off >> 2) + ch, (float)iv * inv_ch);
-                        ++n_at;
+                    for (int jj = 0; jj < 4; ++jj) {                             // the chunk's LDS traffic first, then its four atomics
+                        off[jj] = (unsigned)__shfl((int)g_off[r], 16 * jj + (lane >> 2));   // byte offset of that slot's pixel (view base included)
+                        iv[jj] = pl[16 * jj];
+                        pl[16 * jj] = 0;                                         // ready for the next quad
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const float val = (float)iv[jj] * inv_ch;
+                        const int voff = (int)(off[jj] + ch4);
+                        if constexpr (kExpB & 2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), rgk, voff, q_off, 0);
+                        else if constexpr (kExpB & 1) asm volatile("" :: "v"(val), "v"(voff));
+                        else if constexpr (MASKED) {
+                            unsigned long long save;
+                            asm volatile("s_mov_b64 %[save], exec\n\t"
+                                         "v_cmpx_ne_u32_e32 vcc, 0, %[iv]\n\t"
+                                         "s_cbranch_execz .Lskip%=\n\t"
+                                         "buffer_atomic_add_f32 %[val], %[voff], %[rsrc], %[soff] offen\n\t"
+                                         "s_add_u32 %[cnt], %[cnt], 1\n"
+                                         ".Lskip%=:\n\t"
+                                         "s_mov_b64 exec, %[save]"
+                                         : [save] "=&s"(save), [cnt] "+s"(n_dyn)
+                                         : [iv] "v"(iv[jj]), [val] "v"(val), [voff] "v"(voff), [rsrc] "s"(dgk), [soff] "s"(q_off)
+                                         : "vcc", "scc", "memory");
+                        } else {
+                            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(val, rgk, voff, q_off, 0);
+                            ++n_dyn;
+                        }
                     }
                 }
-            }
+            };
+            if (poisoned) flush(std::false_type{}); else flush(std::true_type{});
             if (tid < 4) sh->aux[(q & 1) * 4 + tid] = 0;                         // read by every wave before the barrier above
             // window q+2 and grad_out q+2 (requested before this quad's atomics) have landed; the atomics stay in flight
-            wait_vmcnt(n_at);
+            EXP_T(3);                                                            // flush issued
+            wait_vmcnt((kExpB & 3) ? 0 : n_dyn);
+            EXP_T(4);                                                            // window q+2 / grad_out q+2 landed
             if constexpr (kExpB & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
             lds_barrier();
+            EXP_T(5);                                                            // barrier 2
         }
+#if MVHMR_EXP_BWD & 64
+        if (lane == 0) {
+            for (int i = 0; i < 6; ++i) atomicAdd(&g_exp_timers[i], t_acc[i]);
+            atomicAdd(&g_exp_timers[6], 1ull);
+        }
+#endif
     } else {
         // ---- windows do not fit: scatter straight to the accumulator (its own function: keeps its registers -- 16 tap
         // offsets on top of the weights -- out of the fast path's allocation, which otherwise spills in the quad loop)
@@ -508,6 +574,15 @@ hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Probl
     return hipGetLastError();
 }
 
+#if MVHMR_EXP_BWD & 64
+extern "C" __attribute__((visibility("default"))) int mvhmr_exp_timers_read(unsigned long long *out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_exp_timers), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_exp_timers), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
+
 bool brick_bwd_supported(const Problem &p)
 {
     if (p.feat_f16 != p.out_f16) return false;                            // fp32 or fp16 storage throughout (or fp32 features with a bf16 volume); other mixes -> gather
@@ -516,6 +591,7 @@ bool brick_bwd_supported(const Problem &p)
     if (p.C % 4) return false;
     if (bwd_brick_z(p) != 16 && (p.Z % kBZ || p.X % kBX || p.Y % (nt / 128))) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
+    if ((long long)p.V * (p.C / 4) * p.H * p.W >= (1ll << 27)) return false;   // one sample's accumulator: 32-bit byte offsets (buffer atomics)
     if (p.N >= (1ll << 28)) return false;
     return true;
 }

@@ -9,3 +9,14 @@ if name != "shipped":
     _capi.LIB_PATH = os.path.join(ROOT, "multiviewhmr_amd", "lib_exp", name, "libmvhmr_unproject.so")
 import bench
 bench.main()
+# experiment builds with phase timers (MVHMR_EXP_BWD bit 6): print them after the run
+import ctypes
+lib = _capi.lib()
+if hasattr(lib, "mvhmr_exp_timers_read"):
+    buf = (ctypes.c_ulonglong * 8)()
+    lib.mvhmr_exp_timers_read(buf, 0)
+    waves = max(1, buf[6]); tot = sum(buf[i] for i in range(6))
+    names = ["resample issued", "scales + DMA request + adds + Jacobian issued", "barrier 1", "flush issued", "vmcnt wait", "barrier 2"]
+    sys.stderr.write("phase timers (s_memtime ticks per wave, whole quad loop; %d waves)\n" % waves)
+    for i in range(6):
+        sys.stderr.write("  %-48s %10.0f  %5.1f %%\n" % (names[i], buf[i] / waves, 100.0 * buf[i] / tot))
