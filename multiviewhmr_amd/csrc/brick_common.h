@@ -112,6 +112,14 @@ __device__ __forceinline__ void lds_add(int *p, int v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// ds_add_u32 (no return) at an absolute LDS byte address + immediate offset.  Outside hipcc's lgkmcnt bookkeeping: completion is
+// the next s_waitcnt lgkmcnt(0) (lds_barrier)
+template <int OFF>
+__device__ __forceinline__ void lds_add_at(unsigned addr, int v)
+{
+    asm volatile("ds_add_u32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
 // floor(x + 0.5) as int32 in one instruction
 __device__ __forceinline__ int round_int(float x)
 {

@@ -194,7 +194,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         for (int i = tid; i < 4 * plane_floats; i += NT) iplanes[i] = 0;
         if (tid < 9) sh->aux[tid] = 0;
 
-        int a0[VT], ws16[VT], ga4[VT];
+        const unsigned plane0 = (unsigned)(size_t)(lds_void_t *)smem + (unsigned)(NBUF * buf_bytes);   // LDS byte address of gradient plane 0
+        int a0[VT], ws16[VT];
+        unsigned ga4[VT], gb4[VT];                                        // LDS byte address of the tap's two rows in gradient plane 0
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             const bool ok = (valid >> v) & 1u;
@@ -205,7 +207,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // still zero head or real slots, where + 0 changes nothing) -- parked on ONE word the lanes would serialise (same-address
             // LDS atomics: 2 cycles per lane), and masking them off instead costs an exec mask + branch per (channel, view) for nothing:
             // an exec-masked ds_add_u32 is as expensive as a full one (scripts/microbench_ldsmask.hip)
-            ga4[v] = (ok ? kZeroSlots + s0 : 2 * lane) * 4;                        // as a byte offset: no shift per use
+            ga4[v] = plane0 + (unsigned)(ok ? kZeroSlots + s0 : 2 * lane) * 4u;
+            gb4[v] = ga4[v] + (unsigned)ws[v] * 4u;
             ws16[v] = ws[v] * 16;
         }
         // ---- chunks of this wave (64 consecutive window slots of one view): DMA source + flush destination
@@ -260,7 +263,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         lds_barrier();                                                           // planes are zero
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
-            int *p = iplanes + (ga4[v] >> 2);
+            int *p = iplanes + ((ga4[v] - plane0) >> 2);
             if ((valid >> v) & 1u) { lds_add(p, 1); lds_add(p + 1, 1); lds_add(p + ws[v], 1); lds_add(p + ws[v] + 1, 1); }
         }
         lds_barrier();
@@ -352,7 +355,10 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // service time then hides under the Jacobian of quad q+1 (VALU only).
             if (q + 1 < nq) resample(q + 1);
             EXP_T(0);                                                            // resample issued (+ loop top)
-            float scale[4], inv_scale[4];
+            // scales: integer arithmetic on wave-uniform values, kept on the scalar unit (the asm operands below are SGPRs) -- as float
+            // selects the compiler built them with ~27 half-rate VALU instructions per quad
+            float scale[4];
+            int inv_bits[4];
             bool poisoned = false;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -360,12 +366,13 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 const int e = ((bbits >> 23) & 0xff) - 126;
                 int se = hbits - e + 127;
                 se = se < 1 ? 1 : (se > 254 ? 254 : se);
-                scale[i] = bbits == 0 ? 0.f : __builtin_bit_cast(float, se << 23);
-                inv_scale[i] = bbits == 0 ? 0.f : __builtin_bit_cast(float, (254 - se) << 23);
+                int sc_bits = bbits == 0 ? 0 : se << 23;
+                inv_bits[i] = bbits == 0 ? 0 : (254 - se) << 23;
                 // a non-finite |ds| somewhere in the brick (overflowed or NaN grad_out): fixed point cannot carry it.  The channel
                 // adds nothing (scale 0) and the flush writes NaN to every live pixel of the brick's windows instead -- a superset
                 // of the pixels the reference's float scatter would poison, so that isfinite() checks downstream still trip.
-                if (bbits >= 0x7f800000) { scale[i] = 0.f; inv_scale[i] = __builtin_nanf(""); poisoned = true; }
+                if (bbits >= 0x7f800000) { sc_bits = 0; inv_bits[i] = 0x7fc00000; poisoned = true; }
+                asm volatile("v_mov_b32 %0, %1" : "=v"(scale[i]) : "s"(sc_bits));
             }
             if (q + 2 < nq) {
                 if (NBUF == 1) lds_barrier();                                    // single buffer: every wave has sampled window q+1
@@ -374,29 +381,32 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // channel by channel: the 16 adds of quad q (fire and forget: the LDS unit retires ~14.5 lane-adds per clock, so a wave
             // issues them at the pace of the whole CU's queue), then the Jacobian of quad q+1 for the same channel (VALU only; it
             // overwrites ds[i], which the adds just issued have read) -- the arithmetic runs while the queue drains
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            // Address operands: the two row addresses of a view are per-lane registers kept for the whole kernel (plane 0, absolute LDS
+            // bytes); the plane and the +1 column are the instruction's immediate offset.  No VALU address arithmetic per add -- a
+            // v_add_u32 with an SGPR operand (the plane base, the row stride) issues at half rate, as does the shift that rebuilt
+            // the byte offset (scripts/microbench_ops.hip).
+            auto adds_of_channel = [&](auto i_tag) __attribute__((always_inline)) {
+                constexpr int i = decltype(i_tag)::value;
+                constexpr int off = i * plane_floats * 4;
+                static_assert(3 * plane_floats * 4 + 4 < 65536, "plane offsets must fit the ds_ immediate");
 #pragma unroll
                 for (int v = 0; v < VT; ++v) {
-                    // two address registers (tap row 0 / row 1); planes and the +1 column are immediate offsets.
-                    // Opaque to the optimiser: hoisted out of the loop they become pinned registers and the kernel spills
-                    int r0 = ga4[v];
-                    asm volatile("" : "+v"(r0));
-                    const int r1 = r0 + ws[v] * 4;
                     if (!(kExpB & 4)) {
                         const float d = ds[i][v] * scale[i];
-                        int *p0 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r0);
-                        int *p1 = reinterpret_cast<int *>(reinterpret_cast<unsigned char *>(iplanes + i * plane_floats) + r1);
-                        lds_add(p0, round_int(d * w00[v]));
-                        lds_add(p0 + 1, round_int(d * w01[v]));
-                        lds_add(p1, round_int(d * w10[v]));
-                        lds_add(p1 + 1, round_int(d * w11[v]));
+                        lds_add_at<off>(ga4[v], round_int(d * w00[v]));
+                        lds_add_at<off + 4>(ga4[v], round_int(d * w01[v]));
+                        lds_add_at<off>(gb4[v], round_int(d * w10[v]));
+                        lds_add_at<off + 4>(gb4[v], round_int(d * w11[v]));
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 if (q + 1 < nq) jacobian1(q + 1, i);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            };
+            adds_of_channel(std::integral_constant<int, 0>{});
+            adds_of_channel(std::integral_constant<int, 1>{});
+            adds_of_channel(std::integral_constant<int, 2>{});
+            adds_of_channel(std::integral_constant<int, 3>{});
             if (q + 2 < nq) load_g(q + 2);
             EXP_T(1);                                                            // scales, DMA request, adds + Jacobian issued
             if constexpr (kExpB & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
@@ -412,7 +422,21 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // serialised behind the LDS read they test, plus the 64-bit address arithmetic of a global_atomic -- 7 slow + 3 fast
             // VALU instructions per element against 2 + 2 here (scripts/loop_histogram.py).
             const int q_off = q * HW * 16;                                       // wave-uniform byte offset of the quad (soffset)
-            const float inv_ch = (lane & 2) ? ((lane & 1) ? inv_scale[3] : inv_scale[2]) : ((lane & 1) ? inv_scale[1] : inv_scale[0]);
+            // 1 / scale of this lane's channel (lane & 3): four scalar values into one register under exec masks (written as a
+            // select chain hipcc turns it into a private array in scratch, indexed by lane & 3)
+            float inv_ch;
+            {
+                unsigned long long save;
+                asm volatile("v_mov_b32 %0, %2\n\t"
+                             "s_mov_b64 %1, exec\n\t"
+                             "s_mov_b64 exec, %6\n\tv_mov_b32 %0, %3\n\t"
+                             "s_mov_b64 exec, %7\n\tv_mov_b32 %0, %4\n\t"
+                             "s_mov_b64 exec, %8\n\tv_mov_b32 %0, %5\n\t"
+                             "s_mov_b64 exec, %1"
+                             : "=&v"(inv_ch), "=&s"(save)
+                             : "s"(inv_bits[0]), "s"(inv_bits[1]), "s"(inv_bits[2]), "s"(inv_bits[3]),
+                               "s"(0x2222222222222222ull), "s"(0x4444444444444444ull), "s"(0x8888888888888888ull));
+            }
             int n_dyn = 0;                                                       // atomic instructions this wave issues for this quad
             auto flush = [&](auto masked_tag) __attribute__((always_inline)) {
                 constexpr bool MASKED = decltype(masked_tag)::value;
