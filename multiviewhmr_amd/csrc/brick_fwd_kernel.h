@@ -29,11 +29,17 @@ namespace mvhmr {
 
 // Timing-only ablations for scripts/exp (never defined in the product build): bit 0 conflict-free fake tap addresses, 1 no tap reads,
 // 2 no LDS-DMA, 3 no stores, 4 no transcendentals, 5 no transpose, 6 no per-quad barrier, 7 no aggregate, 8 no wait for the DMA,
-// 9 LDS-DMA without the m0 save / restore
+// 9 LDS-DMA without the m0 save / restore, 10 phase timers of a brick (s_memtime, summed over all waves: mvhmr_exp_fwd_timers_read)
 #ifndef MVHMR_EXP
 #define MVHMR_EXP 0
 #endif
 constexpr int kExp = MVHMR_EXP;
+#if MVHMR_EXP & 1024
+__device__ unsigned long long g_exp_fwd_timers[8];
+#define EXP_FT(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
+#else
+#define EXP_FT(i) do { } while (0)
+#endif
 
 // lane = 32 g + 16 h + 4 a + b  ->  column h of the wave's two (x-adjacent) columns, z = 16 g + 4 b + a
 __device__ __forceinline__ void fwd_lane_voxel(int lane, int &dcol, int &zin)
@@ -124,6 +130,9 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             int lds_slots, int total_blocks, Gate gate)
 {
     if (gated_off(gate)) return;
+#if MVHMR_EXP & 1024
+    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int BY = NT / 128, NW = NT / 64, BXK = kBX * NVOX;
     constexpr int MC = brick_chunks_per_wave(NT);                                 // DMA chunks a wave may own per quad
     extern __shared__ __align__(16) unsigned char smem[];
@@ -191,7 +200,9 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             }
         }
     }
+    EXP_FT(0);                                                                   // projections staged, tap records, wave boxes
     __syncthreads();
+    EXP_FT(1);                                                                   // barrier: block boxes complete
 
     // ---- window per view (block-uniform): origin, column stride (odd) in slots, first slot; views packed back to back
     int wx0[VT], wy0[VT], ws[VT], nch[VT + 1], slot0[VT];
@@ -327,6 +338,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         }
         for (int q = 0; q < nb - 1 && q < nq; ++q) dma(q);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the zero regions are written
+        EXP_FT(2);                                                               // windows, addresses, chunk table, first DMA issued
         const int a_step = wave & (VT - 1);
         // counted wait at the top of quad q: the DMA of quad q must have landed; at least NVOX stores (and, with three buffers,
         // the n_c DMAs of quad q+1) of this wave are younger.  The first and the last iterations lack part of that order.
@@ -337,6 +349,9 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             constexpr int PAR = decltype(par_tag)::value;
             if constexpr (!(kExp & 256)) { if (q < 2 || q + 1 >= nq) wait_vmcnt(0); else wait_vmcnt(ncw); }
             if constexpr (!(kExp & 64)) bare_barrier();
+#if MVHMR_EXP & 1024
+            if (q == 0) EXP_FT(3);                                               // window 0 landed + barrier
+#endif
             if (nb == 2 && q + 1 < nq) dma(q + 1);
 #pragma unroll
             for (int u = 0; u < NVOX; ++u) {
@@ -385,6 +400,13 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             else fwd_aggregate2<METHOD, VT>(sq[c], sq[c + 1], res[c], res[c + 1]);
         }
         store_quad(nq - 1, NVOX - 1, res);
+        EXP_FT(4);                                                               // the quad loop
+#if MVHMR_EXP & 1024
+        if (lane == 0) {
+            for (int i = 0; i < 5; ++i) atomicAdd(&g_exp_fwd_timers[i], t_acc[i]);
+            atomicAdd(&g_exp_fwd_timers[6], 1ull);
+        }
+#endif
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (clamped taps, zero weights outside)
 #pragma unroll

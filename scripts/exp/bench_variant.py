@@ -20,3 +20,12 @@ if hasattr(lib, "mvhmr_exp_timers_read"):
     sys.stderr.write("phase timers (s_memtime ticks per wave, whole quad loop; %d waves)\n" % waves)
     for i in range(6):
         sys.stderr.write("  %-48s %10.0f  %5.1f %%\n" % (names[i], buf[i] / waves, 100.0 * buf[i] / tot))
+if hasattr(lib, "mvhmr_exp_fwd_timers_read"):
+    buf = (ctypes.c_ulonglong * 8)()
+    lib.mvhmr_exp_fwd_timers_read(buf, 0)
+    waves = max(1, buf[6]); tot = sum(buf[i] for i in range(5))
+    names = ["projections + tap records + wave boxes", "barrier (block boxes)", "windows, addresses, chunk table, first DMA issued",
+             "window 0 landed + barrier", "quad loop"]
+    sys.stderr.write("forward phase timers (s_memtime ticks per wave and brick; %d wave-bricks)\n" % waves)
+    for i in range(5):
+        sys.stderr.write("  %-52s %10.0f  %5.1f %%\n" % (names[i], buf[i] / waves, 100.0 * buf[i] / tot))
