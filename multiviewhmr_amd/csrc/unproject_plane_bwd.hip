@@ -3,24 +3,26 @@
 // reference's shipped VOLUME_SIZE = 16, cfg/defaults.py:25, at 5.8).  The gather backward scatters every tap with a global float
 // atomic there (4 per voxel, view and channel: atomic-rate bound, ~1.3 TB/s of added bytes on gfx950).
 //
-// Here the OUTPUT is what stays on chip: one block owns the gradient plane of one (sample, view, channel quad) -- Hf x Wf pixels x 4
-// channels, 147 KB for 96 x 96 maps -- in LDS, walks every voxel of the sample, re-samples all V views for the aggregate's Jacobian
-// (autograd of models/aggregation.py:55-83, V-fold redundant across the views' blocks), adds only ITS view's four taps into the plane
-// and finally writes the plane once with plain coalesced stores, straight into the caller's planar gradient tensor: no global atomic,
-// no accumulator, no clear, no gradient layout pass.
+// Here the OUTPUT is what stays on chip, in two passes over a tap table:
 //
 //   tap table   k_plane_taps: per (sample, view, voxel) the four bilinear weights and the clamped tap coordinates, computed ONCE
-//               (make_taps: the pinned projection arithmetic with its IEEE divides) instead of by each of the V * C/4 blocks that
-//               visit the voxel; the same kernel counts the taps every pixel receives (the fixed-point headroom, below);
+//               (make_taps: the pinned projection arithmetic with its IEEE divides); the same kernel counts the taps every pixel
+//               receives (the fixed-point headroom, below);
+//   Jacobian    k_plane_ds: one thread per (voxel, channel quad) gathers the taps of all V views once, applies the aggregate's Jacobian
+//               (autograd of models/aggregation.py:55-83) and writes ds = d(aggregate)/d(sample) * grad_out as one float4 per view into
+//               a scratch stream dsW[b][v][quad][voxel] (V x the size of grad_out);
+//   planes      k_bwd_plane: one block owns the gradient plane of one (sample, view, channel quad) -- Hf x Wf pixels x 4 channels,
+//               147 KB for 96 x 96 maps -- in LDS, walks its ds stream and its view's table entries (36 B per voxel, coalesced), adds
+//               the four taps and finally writes the plane once with plain coalesced stores, straight into the caller's planar
+//               gradient tensor: no global atomic, no accumulator, no clear, no gradient layout pass.
+//   (Round 3's first form did the Jacobian inside the plane blocks: every view's block re-sampled all V views, V-fold the gathers,
+//   and the vector L1 was what bound it -- 1.48 ms for configs[1] against 0.3 + 0.2 ms for the two passes.)
+//
 //   plane       planar per channel, row stride Wf | 1 (a z column's taps are Wf-strided rows: an odd stride spreads them over the
-//               banks), int32 FIXED POINT: ds_add_f32 costs ~190 cycles per wave instruction on gfx950, ds_add_u32 4-6.  One
-//               power-of-two scale per channel, fixed BEFORE the walk from a bound on every contribution the block can meet:
-//               |ds| <= max |grad_out| (this sample, this channel) * (1 + R), R = the range the samples of this quad can span
-//               (max(0, feature max) - min(0, feature min) over the V planes: a bilinear sample with zero padding is a sub-convex
-//               combination of its taps; the softmax Jacobian is g p_v (1 + s_v - out), the others are <= |g|), times the plane's
-//               tap multiplicity: no sum can overflow, and the walk needs neither a block-wide reduction nor a barrier -- the waves
-//               drift apart and their gathers, arithmetic and LDS adds overlap.  Resolution: 2^-31 * multiplicity of that bound per
-//               contribution (observed: <= 6e-6 of the largest gradient with ~100 taps per pixel and 2^40 of dynamic range);
+//               banks), int32 FIXED POINT: ds_add_f32 costs ~190 cycles per wave instruction on gfx950, ds_add_u32 4-6.  One scale
+//               per channel, fixed BEFORE the walk from the exact max |ds| of the block's stream (a first pass over it) times the
+//               plane's tap multiplicity: no sum can overflow, and the walk needs neither a block-wide reduction nor a barrier -- the
+//               waves drift apart.  Resolution: 2^-31 * multiplicity of that bound per contribution;
 //   non-finite  an Inf / NaN contribution cannot be carried in fixed point: its pixels are marked in a bit plane and written as NaN
 //               -- exactly the pixels the reference's float scatter poisons (the gather variant's contract).
 // Features are read from the column-major quad-planar fp32 copy (MVHMR_LAYOUT_QUAD: a tap = one 16-B load of 4 channels).
@@ -35,8 +37,7 @@ constexpr int plane_threads(int views) { return views == 8 ? 512 : 1024; }   // 
 constexpr int kPlaneLdsBytes = 160 * 1024 - 512;
 
 struct PlaneShared {
-    int gmax[4];         // max |grad_out| bits per channel of the quad over the sample (finite values only)
-    int fpos, fneg;      // bits of max(0, feature max) and of max(0, -feature min) over the V planes of the quad (finite values only)
+    int gmax[4];         // max |ds| bits per channel of the block's stream (finite values only)
 };
 
 __host__ __device__ inline int plane_row_stride(int W) { return W | 1; }
@@ -81,123 +82,46 @@ k_plane_taps(const float *__restrict__ proj, const Coords coords, float4 *__rest
     if (threadIdx.x == 0) cmax[blockIdx.x] = cnt[HW];
 }
 
-// ------------------------------------------------------------------------------------------------- the plane kernel
-template <int METHOD, int VT, typename TO, typename TF>
-__global__ void __launch_bounds__(plane_threads(VT))
-k_bwd_plane(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, const float4 *__restrict__ tabW,
-            const int *__restrict__ tabX, const int *__restrict__ cmax, TF *__restrict__ grad_features, int C, int H, int W,
-            long long N, Gate gate)
+// ------------------------------------------------------------------------------------------------- the Jacobian pass
+// ds = d(aggregate) / d(sample) * grad_out for every (voxel, view, channel), computed ONCE per (voxel, channel quad): one thread per
+// voxel gathers the taps of all V views (16-B loads from the quad-planar copy), applies the aggregate's Jacobian and writes one float4
+// (the quad's four channels) per view into dsW[b][v][quad][voxel] -- consecutive threads, consecutive voxels: 1-KiB stores.  No LDS,
+// no barrier.  (The first form of the plane backward re-sampled all V views inside every view's plane block: V-fold the gathers, and
+// the vector L1 -- TCP_GATE_EN1 99 % -- was what bound it: profiles/r03_plane_bwd_counters.txt.)
+constexpr int kDsThreads = 256;
+inline int ds_blocks_of(const Problem &p) { return (int)((p.N + kDsThreads - 1) / kDsThreads); }
+
+template <int METHOD, int VT, typename TO>
+__global__ void __launch_bounds__(kDsThreads)
+k_plane_ds(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, const float4 *__restrict__ tabW, const int *__restrict__ tabX,
+           float4 *__restrict__ dsW, int *__restrict__ dsMax, int C, int H, int W, long long N, Gate gate)
 {
     if (gated_off(gate)) return;
-    constexpr int kPlaneThreads = plane_threads(VT);
-    extern __shared__ __align__(16) unsigned char smem[];
-    const int Ws = plane_row_stride(W), cells = H * Ws, mask_words = (cells + 31) >> 5;
-    int *const planes = reinterpret_cast<int *>(smem);                           // [4][cells]
-    unsigned *const poison = reinterpret_cast<unsigned *>(planes + 4 * cells);   // [4][mask_words]
-    PlaneShared *const sh = reinterpret_cast<PlaneShared *>(poison + 4 * mask_words);
-    const int tid = threadIdx.x, lane = tid & 63;
     const int nq = C >> 2, HW = H * W;
-    const int q = blockIdx.x % nq, v_own = (blockIdx.x / nq) % VT, b = blockIdx.x / (nq * VT);
-
-    for (int i = tid; i < 4 * cells + 4 * mask_words; i += kPlaneThreads) planes[i] = 0;      // the bit planes follow the planes
-    if (tid < 4) sh->gmax[tid] = 0;
-    if (tid == 4) { sh->fpos = 0; sh->fneg = 0; }
-    __syncthreads();
-
+    const int q = blockIdx.y, b = blockIdx.z;
+    const bool live = (long long)blockIdx.x * kDsThreads + threadIdx.x < N;
+    const long long n = live ? (long long)blockIdx.x * kDsThreads + threadIdx.x : N - 1;    // tail threads redo the last voxel, store nothing
     const float4 *const fq = featK + ((long long)b * VT * nq + q) * HW;          // view v: + v * nq * HW
     const TO *const gq = grad_out + ((long long)b * C + 4 * q) * N;
     const float4 *const tw = tabW + (long long)b * VT * N;
     const int *const tx = tabX + (long long)b * VT * N;
-    // ---- the bound that fixes the scales (finite values only: a non-finite contribution takes the bit-plane route below).
-    // Non-negative floats order as their bit patterns, so the reductions run on ints.
-    {
-        int gm[4] = {0, 0, 0, 0}, fp = 0, fn = 0;
-        for (long long n = tid; n < N; n += kPlaneThreads)
+    float g[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int bits = __builtin_bit_cast(int, to_f32<TO>(gq[(long long)i * N + n])) & 0x7fffffff;
-                gm[i] = bits < 0x7f800000 && bits > gm[i] ? bits : gm[i];
-            }
-        for (int v = 0; v < (METHOD == AGG_SOFTMAX ? VT : 0); ++v)               // only the softmax Jacobian depends on the samples
-            for (int k = tid; k < HW; k += kPlaneThreads) {
-                const float4 f = fq[(long long)v * nq * HW + k];
-                const float e[4] = {f.x, f.y, f.z, f.w};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int raw = __builtin_bit_cast(int, e[i]), bits = raw & 0x7fffffff;
-                    if (bits < 0x7f800000) { if (raw < 0) fn = bits > fn ? bits : fn; else fp = bits > fp ? bits : fp; }
-                }
-            }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { const int m = wave_max_dpp(gm[i]); if (lane == 0 && m) atomicMax(&sh->gmax[i], m); }
-        const int mp = wave_max_dpp(fp), mn = wave_max_dpp(fn);
-        if (lane == 0) { if (mp) atomicMax(&sh->fpos, mp); if (mn) atomicMax(&sh->fneg, mn); }
-    }
-    __syncthreads();
-    // scale per channel: every contribution is at most bound = gmax * (1 + R) (times 1 + 2^-8 for the rounding of the Jacobian's own
-    // arithmetic), at most `cm` of them meet in one pixel, so with scale = (2^31 - 2^23) / (cm * bound) no sum leaves int32 -- and
-    // nothing of the 31 bits is given away to a power-of-two rounding of the bound or of the multiplicity
-    const int cm = uniform(cmax[b * VT + v_own]);
-    const float range = METHOD == AGG_SOFTMAX ? __builtin_bit_cast(float, uniform(sh->fpos)) + __builtin_bit_cast(float, uniform(sh->fneg)) : 0.f;
-    float scale[4], inv_scale[4];                                                 // 0: every finite grad_out of this channel is zero
-    bool over[4];                                                                 // the bound itself overflows fp32: nothing can be scaled
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float full = (float)cm * (__builtin_bit_cast(float, uniform(sh->gmax[i])) * (1.f + range) * 1.00390625f);
-        const bool ok = full > 0.f && full < 3.0e38f;
-        over[i] = !(full < 3.0e38f);                                              // (inf included): non-zero contributions become NaN pixels
-        scale[i] = uniform(ok ? __fdiv_rn(2139095040.f, full) : 0.f);            // wave-uniform: scalar registers
-        inv_scale[i] = uniform(ok ? __fdiv_rn(full, 2139095040.f) : 0.f);
-    }
-    // a contribution fixed point cannot carry: Inf / NaN, or anything non-zero under an overflowing bound
-    auto uncarried = [&](float dv, int i) __attribute__((always_inline)) {
-        return (__builtin_bit_cast(int, dv) & 0x7fffffff) >= 0x7f800000 || (over[i] && dv != 0.f);
-    };
-    bool any_poison = false;
-
-    // table entries and grad_out of the NEXT chunk are requested before this chunk's arithmetic: the taps' addresses come from the
-    // table, so without the prefetch every chunk pays two dependent memory latencies back to back
-    float4 wn[VT];
-    int xn[VT];
-    float gn[4];
-    auto request = [&](long long n) __attribute__((always_inline)) {
-        const bool in = n < N;
-#pragma unroll
-        for (int v = 0; v < VT; ++v) {
-            wn[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-            xn[v] = 0;
-            if (in) { wn[v] = tw[(long long)v * N + n]; xn[v] = tx[(long long)v * N + n]; }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) gn[i] = in ? to_f32<TO>(gq[(long long)i * N + n]) : 0.f;
-    };
-    constexpr bool kPrefetch = VT <= 4;                                            // 8 views: the second set of entries (48 registers) would spill
-    if constexpr (kPrefetch) request(tid);
-    int chunk = 0;
-    for (long long n0 = 0; n0 < N; n0 += kPlaneThreads, ++chunk) {
-        if constexpr (!kPrefetch) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gn[i] = n0 + tid < N ? to_f32<TO>(gq[(long long)i * N + n0 + tid]) : 0.f;
-        }
-        float s[4][VT];
-        float4 wo = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned xo = 0;
-        // taps of two views in flight at a time (32 registers): the next pair is requested before this pair is folded.  An
-        // identically zero sample reads one dummy pixel (0, 0) with zero weights (the loads stay unconditional); a non-finite pixel
-        // there must not leak, hence the select in the fold
+    for (int i = 0; i < 4; ++i) g[i] = to_f32<TO>(gq[(long long)i * N + n]);
+    float s[4][VT];
+    if constexpr (METHOD == AGG_SOFTMAX || METHOD == AGG_MAX) {                    // sum / mean: the Jacobian does not depend on the samples
+        // taps of two views in flight at a time (32 registers).  An identically zero sample reads one dummy pixel (0, 0) with zero
+        // weights (the loads stay unconditional); a non-finite pixel there must not leak, hence the select in the fold
         constexpr int G = 2;
         f32x4 T[2][G][4];
+        float4 wv[2][G];
         auto gather = [&](int v0, int set) __attribute__((always_inline)) {
 #pragma unroll
             for (int u = 0; u < G; ++u) {
                 const int v = v0 + u;
                 if (v >= VT) continue;
-                if constexpr (!kPrefetch) {                                       // 8 views: a pair's entries right before its taps
-                    wn[v] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    xn[v] = 0;
-                    if (n0 + tid < N) { wn[v] = tw[(long long)v * N + n0 + tid]; xn[v] = tx[(long long)v * N + n0 + tid]; }
-                }
-                const unsigned xy = (unsigned)xn[v];
+                wv[set][u] = tw[(long long)v * N + n];
+                const unsigned xy = (unsigned)tx[(long long)v * N + n];
                 const int x0 = xy & 0x7fff, x1 = x0 + ((xy >> 15) & 1), y0 = (xy >> 16) & 0x7fff, y1 = y0 + (xy >> 31);
                 const float4 *fv = fq + (long long)v * nq * HW;
                 const float4 a = fv[x0 * H + y0], bb = fv[x1 * H + y0], c = fv[x0 * H + y1], d = fv[x1 * H + y1];
@@ -214,8 +138,7 @@ k_bwd_plane(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             for (int u = 0; u < G; ++u) {
                 const int v = v0 + u;
                 if (v >= VT) continue;
-                const float4 w = wn[v];
-                if (v == v_own) { wo = w; xo = (unsigned)xn[v]; }
+                const float4 w = wv[set][u];
                 const bool zero = w.x == 0.f && w.y == 0.f && w.z == 0.f && w.w == 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -224,18 +147,105 @@ k_bwd_plane(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 }
             }
         }
-        // d(aggregate)/d(sample of this block's view) * grad_out, per channel
-        float d[4];
+    } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float ds[VT];
-            aggregate_grad<METHOD, VT>(s[i], gn[i], ds);
-            float dv = ds[0];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int v = 1; v < VT; ++v) dv = v == v_own ? ds[v] : dv;
-            d[i] = dv;
+            for (int v = 0; v < VT; ++v) s[i][v] = 0.f;
+    }
+    float ds[4][VT];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) aggregate_grad<METHOD, VT>(s[i], g[i], ds[i]);
+    float4 *const dst = dsW + ((long long)b * VT * nq + q) * N + n;              // view v: + v * nq * N
+    if (live) {
+#pragma unroll
+        for (int v = 0; v < VT; ++v) dst[(long long)v * nq * N] = make_float4(ds[0][v], ds[1][v], ds[2][v], ds[3][v]);   // plain store: the plane kernel reads it next
+    }
+    // ---- max |ds| per channel over this block's voxels and all views (finite values only: the plane kernel marks the others), for the
+    // fixed-point scale.  Non-negative floats order as their bit patterns.  One int4 per block, no atomics: the plane blocks take the
+    // max over their sample's and quad's entries.
+    __shared__ int wmax[kDsThreads / 64][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int m = 0;
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const int bits = __builtin_bit_cast(int, ds[i][v]) & 0x7fffffff;
+            m = bits < 0x7f800000 && bits > m ? bits : m;
         }
-        if constexpr (kPrefetch) request(n0 + kPlaneThreads + tid);                // in flight under the adds
+        m = wave_max_to_last_row(m);
+        if ((threadIdx.x & 63) == 63) wmax[threadIdx.x >> 6][i] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        int m = wmax[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kDsThreads / 64; ++w) m = wmax[w][threadIdx.x] > m ? wmax[w][threadIdx.x] : m;
+        dsMax[(((long long)b * nq + q) * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = m;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- the plane kernel
+// One block per (sample, view, channel quad): reads its ds stream and its view's tap table (36 B per voxel, coalesced), adds the four
+// taps of every voxel into the LDS plane, writes the plane once.  The fixed-point scale is fixed BEFORE the walk from the max |ds| of
+// the sample's channel (all views: the Jacobian pass leaves one int4 per block) and the plane's tap multiplicity.
+template <typename TF>
+__global__ void __launch_bounds__(1024)
+k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int ds_blocks, const float4 *__restrict__ tabW,
+            const int *__restrict__ tabX, const int *__restrict__ cmax, TF *__restrict__ grad_features, int C, int V, int H, int W, long long N,
+            Gate gate)
+{
+    if (gated_off(gate)) return;
+    constexpr int kPlaneThreads = 1024;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int Ws = plane_row_stride(W), cells = H * Ws, mask_words = (cells + 31) >> 5;
+    int *const planes = reinterpret_cast<int *>(smem);                           // [4][cells]
+    unsigned *const poison = reinterpret_cast<unsigned *>(planes + 4 * cells);   // [4][mask_words]
+    PlaneShared *const sh = reinterpret_cast<PlaneShared *>(poison + 4 * mask_words);
+    const int tid = threadIdx.x;
+    const int nq = C >> 2, HW = H * W;
+    const int q = blockIdx.x % nq, v_own = (blockIdx.x / nq) % V, b = blockIdx.x / (nq * V);
+
+    for (int i = tid; i < 4 * cells + 4 * mask_words; i += kPlaneThreads) planes[i] = 0;      // the bit planes follow the planes
+    if (tid < 4) sh->gmax[tid] = 0;
+    __syncthreads();
+
+    const float4 *const dq = dsW + (((long long)b * V + v_own) * nq + q) * N;
+    const float4 *const tw = tabW + ((long long)b * V + v_own) * N;
+    const int *const tx = tabX + ((long long)b * V + v_own) * N;
+    // ---- max |ds| per channel over the sample's voxels (all views: the Jacobian pass's per-block maxima)
+    {
+        const int *const mq = dsMax + ((long long)b * nq + q) * ds_blocks * 4;
+        int gm = 0;
+        for (int k = tid >> 2; k < ds_blocks; k += kPlaneThreads >> 2) { const int m = mq[k * 4 + (tid & 3)]; gm = m > gm ? m : gm; }
+        if (gm) atomicMax(&sh->gmax[tid & 3], gm);
+    }
+    __syncthreads();
+    // scale per channel: every contribution is at most gmax (weights <= 1), at most `cm` of them meet in one pixel, so with
+    // scale = (2^31 - 2^23) / (cm * gmax) no sum leaves int32 -- and nothing of the 31 bits is given away to a power-of-two rounding
+    const int cm = uniform(cmax[b * V + v_own]);
+    float scale[4], inv_scale[4];                                                 // 0: every finite ds of this channel is zero
+    bool over[4];                                                                 // the bound itself overflows fp32: nothing can be scaled
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float full = (float)cm * __builtin_bit_cast(float, uniform(sh->gmax[i]));
+        const bool ok = full > 0.f && full < 3.0e38f;
+        over[i] = !(full < 3.0e38f);                                              // (inf included): non-zero contributions become NaN pixels
+        scale[i] = uniform(ok ? __fdiv_rn(2139095040.f, full) : 0.f);            // wave-uniform: scalar registers
+        inv_scale[i] = uniform(ok ? __fdiv_rn(full, 2139095040.f) : 0.f);
+    }
+    // a contribution fixed point cannot carry: Inf / NaN, or anything non-zero under an overflowing bound
+    auto uncarried = [&](float dv, int i) __attribute__((always_inline)) {
+        return (__builtin_bit_cast(int, dv) & 0x7fffffff) >= 0x7f800000 || (over[i] && dv != 0.f);
+    };
+    bool any_poison = false;
+
+    for (long long n0 = 0; n0 < N; n0 += kPlaneThreads) {
+        const long long n = n0 + tid;
+        float4 wo = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned xo = 0;
+        if (n < N) { wo = tw[n]; xo = (unsigned)tx[n]; dv = dq[n]; }
+        const float d[4] = {dv.x, dv.y, dv.z, dv.w};
         // ---- this view's four taps into the plane (zero-weight taps -- outside the map, z <= 0 -- receive nothing: they add an
         // integer 0 to a clamped, valid pixel).  A non-finite contribution adds 0 here and marks its pixels below.
         const int x0 = xo & 0x7fff, x1 = x0 + ((xo >> 15) & 1), y0 = (xo >> 16) & 0x7fff, y1 = y0 + (xo >> 31);
@@ -272,7 +282,7 @@ k_bwd_plane(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     __syncthreads();
     // ---- the plane, once, straight into the planar gradient tensor
     const bool poisoned = __syncthreads_or(any_poison ? 1 : 0) != 0;
-    TF *const out = grad_features + (((long long)b * VT + v_own) * C + 4 * q) * HW;
+    TF *const out = grad_features + (((long long)b * V + v_own) * C + 4 * q) * HW;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const float inv = inv_scale[i];
@@ -287,43 +297,53 @@ k_bwd_plane(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     }
 }
 
-template <int METHOD, int VT, typename TO, typename TF>
-hipError_t launch_plane_instance(const float4 *featK, const TO *grad_out, const float4 *tabW, const int *tabX, const int *cmax,
-                                 TF *grad_features, const Problem &p, hipStream_t s)
+template <int METHOD, int VT, typename TO>
+hipError_t launch_ds_instance(const float4 *featK, const TO *grad_out, const float4 *tabW, const int *tabX, float4 *dsW, int *dsMax,
+                              const Problem &p, hipStream_t s)
 {
-    const size_t lds = plane_lds_bytes(p.H, p.W);
-    auto kern = k_bwd_plane<METHOD, VT, TO, TF>;
-    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
-    if (e != hipSuccess) return e;
-    const unsigned grid = (unsigned)(p.B * VT * (p.C / 4));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(plane_threads(VT)), lds, s, featK, grad_out, tabW, tabX, cmax, grad_features, p.C, p.H, p.W, p.N,
+    const dim3 grid((unsigned)ds_blocks_of(p), (unsigned)(p.C / 4), (unsigned)p.B);
+    hipLaunchKernelGGL((k_plane_ds<METHOD, VT, TO>), grid, dim3(kDsThreads), 0, s, featK, grad_out, tabW, tabX, dsW, dsMax, p.C, p.H, p.W, p.N,
                        make_gate(p, false));
     return hipGetLastError();
 }
 
-template <int METHOD, typename TO, typename TF>
-hipError_t launch_plane_views(const float4 *featK, const TO *go, const float4 *tabW, const int *tabX, const int *cmax, TF *gf,
-                              const Problem &p, hipStream_t s)
+template <int METHOD, typename TO>
+hipError_t launch_ds_views(const float4 *featK, const TO *go, const float4 *tabW, const int *tabX, float4 *dsW, int *dsMax, const Problem &p,
+                           hipStream_t s)
 {
     switch (p.V) {
-    case 2: return launch_plane_instance<METHOD, 2, TO, TF>(featK, go, tabW, tabX, cmax, gf, p, s);
-    case 4: return launch_plane_instance<METHOD, 4, TO, TF>(featK, go, tabW, tabX, cmax, gf, p, s);
-    case 8: return launch_plane_instance<METHOD, 8, TO, TF>(featK, go, tabW, tabX, cmax, gf, p, s);
+    case 2: return launch_ds_instance<METHOD, 2, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
+    case 4: return launch_ds_instance<METHOD, 4, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
+    case 8: return launch_ds_instance<METHOD, 8, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
     }
     return hipErrorNotSupported;
 }
 
-template <typename TO, typename TF>
-hipError_t launch_plane_method(const float4 *featK, const TO *go, const float4 *tabW, const int *tabX, const int *cmax, TF *gf,
-                               const Problem &p, hipStream_t s)
+template <typename TO>
+hipError_t launch_ds_method(const float4 *featK, const TO *go, const float4 *tabW, const int *tabX, float4 *dsW, int *dsMax, const Problem &p,
+                            hipStream_t s)
 {
     switch (p.method) {
-    case AGG_SOFTMAX: return launch_plane_views<AGG_SOFTMAX, TO, TF>(featK, go, tabW, tabX, cmax, gf, p, s);
-    case AGG_SUM: return launch_plane_views<AGG_SUM, TO, TF>(featK, go, tabW, tabX, cmax, gf, p, s);
-    case AGG_MEAN: return launch_plane_views<AGG_MEAN, TO, TF>(featK, go, tabW, tabX, cmax, gf, p, s);
-    case AGG_MAX: return launch_plane_views<AGG_MAX, TO, TF>(featK, go, tabW, tabX, cmax, gf, p, s);
+    case AGG_SOFTMAX: return launch_ds_views<AGG_SOFTMAX, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
+    case AGG_SUM: return launch_ds_views<AGG_SUM, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
+    case AGG_MEAN: return launch_ds_views<AGG_MEAN, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
+    case AGG_MAX: return launch_ds_views<AGG_MAX, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
     }
     return hipErrorInvalidValue;
+}
+
+template <typename TF>
+hipError_t launch_plane_instance(const float4 *dsW, const int *dsMax, const float4 *tabW, const int *tabX, const int *cmax, TF *grad_features,
+                                 const Problem &p, hipStream_t s)
+{
+    const size_t lds = plane_lds_bytes(p.H, p.W);
+    auto kern = k_bwd_plane<TF>;
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)(p.B * p.V * (p.C / 4));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, dsW, dsMax, ds_blocks_of(p), tabW, tabX, cmax, grad_features, p.C, p.V, p.H, p.W, p.N,
+                       make_gate(p, false));
+    return hipGetLastError();
 }
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -338,15 +358,18 @@ bool plane_bwd_supported(const Problem &p)
     if (plane_lds_bytes(p.H, p.W) > (size_t)kPlaneLdsBytes) return false;        // 96 x 96 maps: 149 KB
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;   // 32-bit tap offsets into the staged copy
     if ((long long)p.B * p.V * (p.C / 4) >= (1ll << 31) || p.B > 65535) return false;
-    if (plane_table_bytes(p) > ((size_t)1 << 30)) return false;                  // a fine grid forced onto this path: keep the old scatter
+    if (p.N >= (1ll << 31) / 1024 * 1024 || p.C / 4 > 65535) return false;       // grid dimensions of the Jacobian pass
+    if (plane_table_bytes(p) > ((size_t)4 << 30)) return false;                  // a fine grid forced onto this path: keep the old scatter
     return true;
 }
 
-// [ weights float4 (B,V,N) | packed tap coordinates int (B,V,N) | max tap count int (B,V) ]
+// [ weights float4 (B,V,N) | packed tap coordinates int (B,V,N) | max tap count int (B,V) | ds float4 (B,V,C/4,N) |
+//   max |ds| int4 (B, C/4, blocks of the Jacobian pass) ]
 size_t plane_table_bytes(const Problem &p)
 {
     const size_t bvn = (size_t)p.B * p.V * (size_t)p.N;
-    return align256(bvn * sizeof(float4)) + align256(bvn * sizeof(int)) + align256((size_t)p.B * p.V * sizeof(int));
+    return align256(bvn * sizeof(float4)) + align256(bvn * sizeof(int)) + align256((size_t)p.B * p.V * sizeof(int)) +
+           align256(bvn * (size_t)(p.C / 4) * sizeof(float4)) + align256((size_t)p.B * (p.C / 4) * ds_blocks_of(p) * 4 * sizeof(int));
 }
 
 // featK: column-major quad-planar fp32 copy of the features; grad_features: the caller's PLANAR gradient tensor (B,V,C,Hf,Wf), every
@@ -360,17 +383,22 @@ hipError_t launch_bwd_plane(const void *featK, const void *grad_out, const float
     float4 *tabW = reinterpret_cast<float4 *>(t);
     int *tabX = reinterpret_cast<int *>(t + align256(bvn * sizeof(float4)));
     int *cmax = reinterpret_cast<int *>(t + align256(bvn * sizeof(float4)) + align256(bvn * sizeof(int)));
+    unsigned char *t3 = t + align256(bvn * sizeof(float4)) + align256(bvn * sizeof(int)) + align256((size_t)p.B * p.V * sizeof(int));
+    float4 *dsW = reinterpret_cast<float4 *>(t3);
+    int *dsMax = reinterpret_cast<int *>(t3 + align256(bvn * (size_t)(p.C / 4) * sizeof(float4)));
     const Gate gate = make_gate(p, false);
     hipLaunchKernelGGL(k_plane_taps, dim3((unsigned)(p.B * p.V)), dim3(1024), (size_t)(p.H * p.W + 1) * sizeof(int), s, proj, coords, tabW, tabX, cmax,
                        p.V, p.H, p.W, p.N, gate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const float4 *fk = static_cast<const float4 *>(featK);
-    if (p.out_bf16) return p.feat_f16 ? hipErrorNotSupported : launch_plane_method<bf16_t, float>(fk, (const bf16_t *)grad_out, tabW, tabX, cmax, (float *)grad_features, p, s);
-    if (!p.out_f16 && !p.feat_f16) return launch_plane_method<float, float>(fk, (const float *)grad_out, tabW, tabX, cmax, (float *)grad_features, p, s);
-    if (p.out_f16 && p.feat_f16) return launch_plane_method<__half, __half>(fk, (const __half *)grad_out, tabW, tabX, cmax, (__half *)grad_features, p, s);
-    if (!p.out_f16 && p.feat_f16) return launch_plane_method<float, __half>(fk, (const float *)grad_out, tabW, tabX, cmax, (__half *)grad_features, p, s);
-    return hipErrorNotSupported;
+    // the Jacobian pass (grad_out's storage type), then the planes (the gradient's storage type)
+    if (p.out_bf16) e = p.feat_f16 ? hipErrorNotSupported : launch_ds_method<bf16_t>(fk, (const bf16_t *)grad_out, tabW, tabX, dsW, dsMax, p, s);
+    else if (p.out_f16) e = launch_ds_method<__half>(fk, (const __half *)grad_out, tabW, tabX, dsW, dsMax, p, s);
+    else e = launch_ds_method<float>(fk, (const float *)grad_out, tabW, tabX, dsW, dsMax, p, s);
+    if (e != hipSuccess) return e;
+    if (p.feat_f16) return launch_plane_instance<__half>(dsW, dsMax, tabW, tabX, cmax, (__half *)grad_features, p, s);
+    return launch_plane_instance<float>(dsW, dsMax, tabW, tabX, cmax, (float *)grad_features, p, s);
 }
 
 }  // namespace mvhmr

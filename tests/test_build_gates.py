@@ -77,20 +77,23 @@ def test_check_loops_covers_the_backward_accumulation_loop(tmp_path):
 
 def test_plane_backward_has_no_global_atomics_in_its_isa(tmp_path):
     """the coarse-grid backward accumulates in LDS and writes plain stores.  Disassemble the unit for gfx950 (hipcc
-    cross-compiles without a GPU) and look at the k_bwd_plane functions."""
+    cross-compiles without a GPU) and look at its three kernel families: the tap table, the Jacobian pass (k_plane_ds: plain stores
+    only) and the plane kernel (k_bwd_plane: 16 LDS adds per voxel, plain stores)."""
     asm = tmp_path / "plane.s"
     subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-munsafe-fp-atomics",
                            "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-S", "--cuda-device-only", "-o", str(asm),
                            os.path.join(CSRC, "unproject_plane_bwd.hip")], stderr=subprocess.DEVNULL)
-    inside, funcs, adds = None, 0, 0
+    inside, planes, jacobians, adds = None, 0, 0, 0
     for line in asm.read_text().splitlines():
         ls = line.strip()
-        if ls.startswith("_ZN5mvhmr") and "k_bwd_plane" in ls and ls.endswith(":") is False and ":" in ls:
+        if ls.startswith("_ZN5mvhmr") and ("k_bwd_plane" in ls or "k_plane_ds" in ls or "k_plane_taps" in ls) and ls.endswith(":") is False and ":" in ls:
             inside = ls.split(":")[0]
-            funcs += 1
+            planes += "k_bwd_plane" in inside
+            jacobians += "k_plane_ds" in inside
         elif ls.startswith(".Lfunc_end"):
             inside = None
         elif inside and not ls.startswith(";"):
             assert "global_atomic" not in ls and "buffer_atomic" not in ls and "flat_atomic" not in ls, (inside, ls)
-            adds += ls.startswith("ds_add_u32")
-    assert funcs >= 12 and adds >= 16 * funcs                                     # 4 methods x 3 view counts x storage types; 16 LDS adds each
+            adds += "k_bwd_plane" in inside and ls.startswith("ds_add_u32")
+    assert planes == 2 and adds >= 16 * planes                                     # fp32 / fp16 gradient storage; 16 LDS adds per voxel
+    assert jacobians >= 4 * 3 * 3                                                  # 4 methods x 3 view counts x 3 grad_out storage types
