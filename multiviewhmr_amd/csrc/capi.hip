@@ -387,31 +387,33 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
         if (rc != MVHMR_OK) return rc;
         const bool quad = desc->feat_layout == MVHMR_LAYOUT_QUAD;
         if (bwd_uses_plane(desc, p)) {
-            // brick side: row-major quad copy, LDS windows, float-atomic flush into `acc`, layout pass; gather side: the plane kernel on
-            // the column-major quad copy (the caller's own when the features came quad-planar), its tap table where `acc` would be
-            rc = launched(quad ? launch_quad_transpose(features, ws, p.B * p.V * (p.C / 4), p.H, p.W, make_gate(p, true), s)
-                               : launch_to_quad_planar(features, ws, p, s), "layout pass");
-            if (rc != MVHMR_OK) return rc;
+            // both sides read the column-major quad copy (the caller's own when the features came quad-planar).  Brick side: LDS windows,
+            // float-atomic flush into `acc`, layout pass; gather side: the plane kernels, their scratch where `acc` would be
             if (!quad) {
-                rc = launched(launch_to_quad_planar_t(features, ws, p, s, false), "layout pass");
+                Problem pu = p;
+                pu.gate_count = nullptr;                                         // not gated: either side needs the copy
+                rc = launched(launch_to_quad_planar_t(features, ws, pu, s, true), "layout pass");
                 if (rc != MVHMR_OK) return rc;
             }
+            const void *featK = quad ? features : ws;
             hipError_t e = hipMemsetAsync(acc, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
             if (e != hipSuccess) return launched(e, "gradient clear");
-            rc = launched(launch_bwd_brick(ws, grad_out, proj, coords, acc, p, s), "brick backward");
+            rc = launched(launch_bwd_brick(featK, grad_out, proj, coords, acc, p, s), "brick backward");
             if (rc != MVHMR_OK) return rc;
             rc = launched(launch_quad_grad_to_planar(acc, grad_features, p, s), "gradient layout pass");
             if (rc != MVHMR_OK) return rc;
-            return launched(launch_bwd_plane(quad ? features : ws, grad_out, proj, coords, grad_features, acc, p, s), "plane backward");
+            return launched(launch_bwd_plane(featK, grad_out, proj, coords, grad_features, acc, p, s), "plane backward");
         }
-        rc = launched(quad ? launch_quad_transpose(features, ws, p.B * p.V * (p.C / 4), p.H, p.W, make_gate(p, true), s)
-                           : launch_to_quad_planar(features, ws, p, s), "layout pass");
-        if (rc != MVHMR_OK) return rc;
+        // brick side: the column-major quad copy (the caller's own when the features came quad-planar); gather side: channels-last
+        if (!quad) {
+            rc = launched(launch_to_quad_planar_t(features, ws, p, s, true), "layout pass");
+            if (rc != MVHMR_OK) return rc;
+        }
         rc = launched(quad ? launch_quad_to_channels_last(features, ws, p, s) : launch_to_channels_last(features, ws, p, s), "layout pass");
         if (rc != MVHMR_OK) return rc;
         hipError_t e = hipMemsetAsync(acc, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
         if (e != hipSuccess) return launched(e, "gradient clear");
-        rc = launched(launch_bwd_brick(ws, grad_out, proj, coords, acc, p, s), "brick backward");
+        rc = launched(launch_bwd_brick(quad ? features : ws, grad_out, proj, coords, acc, p, s), "brick backward");
         if (rc != MVHMR_OK) return rc;
         rc = launched(launch_bwd_gather(grad_out, ws, proj, coords, acc, p, s), "gather backward");
         if (rc != MVHMR_OK) return rc;
@@ -421,13 +423,15 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
     }
     if (bwd_uses_brick(desc, p)) {
         float *gradK = reinterpret_cast<float *>(ws + brick_workspace_bytes(p));
-        rc = desc->feat_layout == MVHMR_LAYOUT_QUAD
-                 ? launched(launch_quad_transpose(features, ws, p.B * p.V * (p.C / 4), p.H, p.W, Gate{nullptr, 0, 1}, s), "layout pass")   // column-major copy -> row-major
-                 : launched(launch_to_quad_planar(features, ws, p, s), "layout pass");
-        if (rc != MVHMR_OK) return rc;
+        const void *featK = features;                                            // quad-planar features: the copy as it is (column-major)
+        if (desc->feat_layout != MVHMR_LAYOUT_QUAD) {
+            rc = launched(launch_to_quad_planar_t(features, ws, p, s, true), "layout pass");
+            if (rc != MVHMR_OK) return rc;
+            featK = ws;
+        }
         hipError_t e = hipMemsetAsync(gradK, 0, (size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float), s);
         if (e != hipSuccess) return launched(e, "gradient clear");
-        rc = launched(launch_bwd_brick(ws, grad_out, proj, coords, gradK, p, s), "brick backward");
+        rc = launched(launch_bwd_brick(featK, grad_out, proj, coords, gradK, p, s), "brick backward");
         if (rc != MVHMR_OK) return rc;
         return launched(launch_quad_grad_to_planar(gradK, grad_features, p, s), "gradient layout pass");
     }

@@ -50,7 +50,7 @@ hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const floa
 
 // brick variant (LDS-staged windows); launches return hipErrorNotSupported when the shape does not qualify.
 //   forward : column-major quad-planar staged copy (launch_to_quad_planar_t), 4*nvox x (NT/128) x 32 bricks
-//   backward: row-major quad-planar staged copy (launch_to_quad_planar), 4 x (NT/128) x 32 bricks
+//   backward: the same column-major quad-planar staged copy, 8 x 8 x 16 (8 x 4 x 16 for 8 views) or 4 x (NT/128) x 32 bricks
 bool brick_fwd_supported(const Problem &p);
 bool brick_bwd_supported(const Problem &p);
 size_t brick_workspace_bytes(const Problem &p);

@@ -68,7 +68,7 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
         const int x0 = t.rx0 < 0 ? 0 : t.rx0, y0 = t.ry0 < 0 ? 0 : t.ry0;
         const int x1 = t.rx0 + 1 > W - 1 ? W - 1 : t.rx0 + 1, y1 = t.ry0 + 1 > H - 1 ? H - 1 : t.ry0 + 1;
         const int base = (v * nq) * HW;
-        o00[v] = base + y0 * W + x0; o01[v] = base + y0 * W + x1; o10[v] = base + y1 * W + x0; o11[v] = base + y1 * W + x1;
+        o00[v] = base + x0 * H + y0; o01[v] = base + x1 * H + y0; o10[v] = base + x0 * H + y1; o11[v] = base + x1 * H + y1;   // column-major copy
     }
     for (int q = 0; q < nq; ++q) {
         const float4 *src = fk + (long long)q * HW;
@@ -143,13 +143,18 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     {
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
+            // The windows are COLUMN-major like the forward's and like the staged copy (B,V,C/4,W,H,4): from here on the kernel works
+            // on the transposed image -- "x" is the image row index y (the fast axis of the copy), "y" the column index x, Wt = H
+            // columns, Ht = W rows -- so every line below reads as the row-major algorithm it was written as.  (Windows along the
+            // other axis: 13.2 instead of 13.75 ms at the north star, whose volume z axis projects onto image y; and the fused route's
+            // quad-planar copy is used as it is.)
             const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
-            w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
-            tx[v] = t.rx0; ty[v] = t.ry0;
+            w00[v] = t.w00; w01[v] = t.w10; w10[v] = t.w01; w11[v] = t.w11;
+            tx[v] = t.ry0; ty[v] = t.rx0;
             if (t.any) valid |= 1u << v;
             const int big = 1 << 30;
-            const int xmin = wave_min(t.any ? t.rx0 : big), ymin = wave_min(t.any ? t.ry0 : big);
-            const int xmax = wave_max(t.any ? t.rx0 : -big), ymax = wave_max(t.any ? t.ry0 : -big);
+            const int xmin = wave_min(t.any ? t.ry0 : big), ymin = wave_min(t.any ? t.rx0 : big);
+            const int xmax = wave_max(t.any ? t.ry0 : -big), ymax = wave_max(t.any ? t.rx0 : -big);
             if (lane == 0 && xmax >= xmin) {
                 atomicMin(&sh->bbox[v][0], xmin); atomicMin(&sh->bbox[v][1], ymin);
                 atomicMax(&sh->bbox[v][2], xmax); atomicMax(&sh->bbox[v][3], ymax);
@@ -228,9 +233,10 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 const int jj = c - c0, slot = (jj << 6) + lane;
                 const int py = slot / sv, px = slot - py * sv;
                 const int gx = ox + px, gy = oy + py;
-                const unsigned live = (px < bw && py < bh && gx >= 0 && gx < W && gy >= 0 && gy < H) ? 1u : 0u;
-                const int cx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx), cy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-                g_off[r] = ((unsigned)((v * nq) * HW + cy * W + cx) * 16u) | (live ? 0u : 0x80000000u);
+                const int Wt = H, Ht = W;                                        // transposed image (see the tap records)
+                const unsigned live = (px < bw && py < bh && gx >= 0 && gx < Wt && gy >= 0 && gy < Ht) ? 1u : 0u;
+                const int cx = gx < 0 ? 0 : (gx > Wt - 1 ? Wt - 1 : gx), cy = gy < 0 ? 0 : (gy > Ht - 1 ? Ht - 1 : gy);
+                g_off[r] = ((unsigned)((v * nq) * HW + cy * Wt + cx) * 16u) | (live ? 0u : 0x80000000u);
                 l_dst[r] = kZeroBytes + (s0 + (jj << 6)) * 16;
                 c_slot[r] = kZeroSlots + s0 + (jj << 6);
             }
@@ -500,20 +506,35 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     }
 }
 
-// fp32 quad-planar accumulator (BV, C/4, HW, 4) -> planar gradient (BV, C, HW)
-template <typename TF>
-__global__ void __launch_bounds__(256)
-k_quad_planar_to_planar(const float4 *__restrict__ src, TF *__restrict__ dst, int C, int HW, Gate gate)
+// fp32 COLUMN-major quad-planar accumulator (BV, C/4, W, H, 4) -> planar gradient (BV, C, H, W).  One block = a band of 32 image
+// columns of one channel quad, read linearly (the band is contiguous: 32 * H float4) and turned through LDS; written as 128-B runs
+// along x per channel and row.
+template <typename TF, int BW>
+__global__ void __launch_bounds__(512)
+k_quad_planar_to_planar(const float4 *__restrict__ src, TF *__restrict__ dst, int C, int H, int W, Gate gate)
 {
     if (gated_off(gate)) return;
+    extern __shared__ float tile[];                                              // [4][H][BW + 1]
+    constexpr int TS = BW + 1;
     const long long bv = blockIdx.z;
-    const int q = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    const float4 g = src[(bv * (C >> 2) + q) * HW + p];
-    TF *d = dst + (bv * C + q * 4) * HW + p;
-    d[0] = from_f32<TF>(g.x); d[HW] = from_f32<TF>(g.y); d[2 * (long long)HW] = from_f32<TF>(g.z); d[3 * (long long)HW] = from_f32<TF>(g.w);
+    const int q = blockIdx.y, x0 = blockIdx.x * BW;
+    const int cols = W - x0 < BW ? W - x0 : BW;
+    const float4 *s = src + ((bv * (C >> 2) + q) * W + x0) * (long long)H;
+    for (int i = threadIdx.x; i < cols * H; i += 512) {
+        const float4 g = s[i];
+        const int xl = i / H, y = i - xl * H;
+        float *t = tile + y * TS + xl;
+        t[0] = g.x; t[H * TS] = g.y; t[2 * H * TS] = g.z; t[3 * H * TS] = g.w;
+    }
+    __syncthreads();
+    TF *d = dst + (bv * C + q * 4) * (long long)H * W + x0;
+    const int xl = threadIdx.x & (BW - 1);
+    if (xl < cols)
+        for (int r = threadIdx.x / BW; r < 4 * H; r += 512 / BW) d[(long long)r * W + xl] = from_f32<TF>(tile[r * TS + xl]);   // r = channel * H + y
 }
+
+// band width of the gradient layout pass: 32 columns where 4 x H x 33 floats fit 64 KB of LDS (H <= 124), else 8
+inline int grad_band(const Problem &p) { return (size_t)4 * p.H * 33 * sizeof(float) <= 64 * 1024 ? 32 : 8; }
 
 namespace {
 constexpr int kNTb = 1024;                            // 2 / 4 views
@@ -591,21 +612,20 @@ hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float
 hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Problem &p, hipStream_t s)
 {
     if (p.C % 4) return hipErrorNotSupported;
-    const int HW = p.H * p.W;
-    const dim3 grid((HW + 255) / 256, p.C / 4, p.B * p.V);
-    if (p.feat_f16) hipLaunchKernelGGL(k_quad_planar_to_planar<__half>, grid, dim3(256), 0, s, (const float4 *)gradK, (__half *)dst, p.C, HW, make_gate(p, true));
-    else hipLaunchKernelGGL(k_quad_planar_to_planar<float>, grid, dim3(256), 0, s, (const float4 *)gradK, (float *)dst, p.C, HW, make_gate(p, true));
+    const int bw = grad_band(p);
+    const dim3 grid((p.W + bw - 1) / bw, p.C / 4, p.B * p.V);
+    const size_t lds = (size_t)4 * p.H * (bw + 1) * sizeof(float);
+    const float4 *g = (const float4 *)gradK;
+    const Gate gate = make_gate(p, true);
+    if (bw == 32) {
+        if (p.feat_f16) hipLaunchKernelGGL((k_quad_planar_to_planar<__half, 32>), grid, dim3(512), lds, s, g, (__half *)dst, p.C, p.H, p.W, gate);
+        else hipLaunchKernelGGL((k_quad_planar_to_planar<float, 32>), grid, dim3(512), lds, s, g, (float *)dst, p.C, p.H, p.W, gate);
+    } else {
+        if (p.feat_f16) hipLaunchKernelGGL((k_quad_planar_to_planar<__half, 8>), grid, dim3(512), lds, s, g, (__half *)dst, p.C, p.H, p.W, gate);
+        else hipLaunchKernelGGL((k_quad_planar_to_planar<float, 8>), grid, dim3(512), lds, s, g, (float *)dst, p.C, p.H, p.W, gate);
+    }
     return hipGetLastError();
 }
-
-#if MVHMR_EXP_BWD & 64
-extern "C" __attribute__((visibility("default"))) int mvhmr_exp_timers_read(unsigned long long *out, int reset)
-{
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_exp_timers), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_exp_timers), z, sizeof(z)) != hipSuccess) return -1; }
-    return 0;
-}
-#endif
 
 bool brick_bwd_supported(const Problem &p)
 {
@@ -617,6 +637,7 @@ bool brick_bwd_supported(const Problem &p)
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
     if ((long long)p.V * (p.C / 4) * p.H * p.W >= (1ll << 27)) return false;   // one sample's accumulator: 32-bit byte offsets (buffer atomics)
     if (p.N >= (1ll << 28)) return false;
+    if ((size_t)4 * p.H * 9 * sizeof(float) > 64 * 1024) return false;           // the gradient layout pass turns column bands through LDS (H <= 455)
     return true;
 }
 
@@ -625,7 +646,7 @@ GateGeom brick_bwd_gate_geom(const Problem &p)
     const int nt = p.V == 8 ? kNTb8 : kNTb;
     GateGeom g;
     g.bz = bwd_brick_z(p);
-    g.bx = bwd_brick_x(g.bz); g.by = nt / (g.bz * g.bx); g.column_major = 0; g.view_group = 0;
+    g.bx = bwd_brick_x(g.bz); g.by = nt / (g.bz * g.bx); g.column_major = 1; g.view_group = 0;
     g.cap_slots = bwd_cap_slots(nt, g.bz);
     g.max_chunks = brick_chunks_per_wave(nt) * (nt / 64);
     return g;
