@@ -208,6 +208,8 @@ def test_brick_softmax_over_the_whole_float_range(views, gpu):
     dict(B=2, V=8, C=16, H=24, W=24, vol=(8, 8, 32)),         # 8 views: 512-thread bricks, one feature window in LDS (fits: 2 500 of 4 900)
     dict(B=1, V=8, C=8, H=16, W=16, vol=(4, 4, 64)),          # 8 views, two z bricks (fits)
     dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views, overflow: out-of-line path
+    dict(B=1, V=4, C=8, H=24, W=40, vol=(8, 8, 32)),          # non-square maps (column-major windows), W not a multiple of the 32-column gradient band
+    dict(B=1, V=2, C=8, H=136, W=20, vol=(8, 8, 32)),         # tall maps: the gradient layout pass falls back to 8-column bands
 ])
 @pytest.mark.parametrize("mode", MODES)
 def test_brick_backward_vs_oracle(shape, mode, gpu):
