@@ -258,37 +258,4 @@ hipError_t launch_conv1x1_wgrad(const float *gy, const float *x, float *dW, floa
     return hipGetLastError();
 }
 
-// column-major quad-planar (BV, C/4, W, H, 4) -> row-major quad-planar (BV, C/4, H, W, 4): what the brick backward stages, when the
-// forward kept only the fused copy.  32 x 32 pixel tiles through LDS, 512-B runs both ways.
-__global__ void __launch_bounds__(256)
-k_quad_transpose(const float4 *__restrict__ src, float4 *__restrict__ dst, int H, int W, int tiles, Gate gate)
-{
-    if (gated_off(gate)) return;
-    __shared__ float4 tile[32][33];
-    const int tile_id = blockIdx.x % tiles;                                      // planes ride in grid.x too: B * V * C / 4 can exceed the 65 535 of grid.z
-    const long long plane = (long long)(blockIdx.x / tiles) * H * W;
-    const int tiles_x = (W + 31) >> 5;
-    const int x0 = (tile_id % tiles_x) << 5, y0 = (tile_id / tiles_x) << 5;
-    const int t0 = threadIdx.x & 31, t1 = threadIdx.x >> 5;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int xx = t1 + 8 * i, x = x0 + xx, y = y0 + t0;                     // lanes along y: contiguous in the source
-        if (x < W && y < H) tile[xx][t0] = src[plane + (long long)x * H + y];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int yy = t1 + 8 * i, y = y0 + yy, x = x0 + t0;                     // lanes along x: contiguous in the destination
-        if (x < W && y < H) dst[plane + (long long)y * W + x] = tile[t0][yy];
-    }
-}
-
-hipError_t launch_quad_transpose(const void *src, void *dst, int planes, int H, int W, const Gate &gate, hipStream_t s)
-{
-    const int tiles = ((W + 31) / 32) * ((H + 31) / 32);
-    if ((long long)tiles * planes >= (1ll << 31)) return hipErrorNotSupported;
-    hipLaunchKernelGGL(k_quad_transpose, dim3((unsigned)(tiles * planes)), dim3(256), 0, s, (const float4 *)src, (float4 *)dst, H, W, tiles, gate);
-    return hipGetLastError();
-}
-
 }  // namespace mvhmr

@@ -54,7 +54,6 @@ hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const floa
 bool brick_fwd_supported(const Problem &p);
 bool brick_bwd_supported(const Problem &p);
 size_t brick_workspace_bytes(const Problem &p);
-hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, hipStream_t s);
 hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s, bool brick_side = true);
 hipError_t launch_fwd_brick(const void *featK, const float *proj, const Coords &coords, void *out, const Problem &p,
                             hipStream_t s);
@@ -94,8 +93,6 @@ hipError_t launch_conv1x1_wgrad(const float *gy, const float *x, float *dW, floa
 hipError_t launch_conv1x1_planar(const float *x, const float *w, const float *bias, float *dst, int BV, int Cin, int Cout, int HW, hipStream_t s);
 hipError_t launch_conv1x1_quad(const float *x, const float *w, const float *bias, void *dst, int BV, int Cin, int Cout, int H, int W,
                                hipStream_t s);
-// column-major quad-planar -> row-major quad-planar (planes = B * V * C / 4); gated like the brick kernels
-hipError_t launch_quad_transpose(const void *src, void *dst, int planes, int H, int W, const Gate &gate, hipStream_t s);
 
 // DLT triangulation of one point per sample (fp32 in / out, float64 inside); points (V,2) shared or (B,V,2) per sample
 hipError_t launch_triangulate_dlt(const float *proj, const float *points, float *out, int B, int V, int points_per_sample, hipStream_t s);

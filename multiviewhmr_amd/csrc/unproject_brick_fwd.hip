@@ -36,20 +36,6 @@ k_to_quad_planar_t(const TF *__restrict__ src, float4 *__restrict__ dst, int C, 
     }
 }
 
-// features (BV, C, HW) -> fp32 (BV, C/4, HW, 4): ROW-major quad-planar, what the brick backward stages
-template <typename TF>
-__global__ void __launch_bounds__(256)
-k_to_quad_planar(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int HW, Gate gate)
-{
-    if (gated_off(gate)) return;
-    const long long bv = blockIdx.z;
-    const int q = blockIdx.y;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= HW) return;
-    const TF *s = src + (bv * C + q * 4) * HW + p;
-    dst[(bv * (C >> 2) + q) * HW + p] = make_float4(to_f32<TF>(s[0]), to_f32<TF>(s[HW]), to_f32<TF>(s[2 * (long long)HW]), to_f32<TF>(s[3 * (long long)HW]));
-}
-
 // Same pass for maps whose 32-row bands fit LDS: a band of one channel quad is 4 x 32 x W contiguous floats per channel, read
 // linearly (1-KiB runs per wave instruction instead of 128-B tile rows) and written as 512-B runs along y.
 template <typename TF>
@@ -112,16 +98,6 @@ hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p,
     const dim3 grid(((p.W + 31) / 32) * ((p.H + 31) / 32), p.C / 4, p.B * p.V);
     if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, gate);
     else hipLaunchKernelGGL(k_to_quad_planar_t<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, gate);
-    return hipGetLastError();
-}
-
-hipError_t launch_to_quad_planar(const void *src, void *dst, const Problem &p, hipStream_t s)
-{
-    if (p.C % 4) return hipErrorNotSupported;
-    const int HW = p.H * p.W;
-    const dim3 grid((HW + 255) / 256, p.C / 4, p.B * p.V);
-    if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, HW, make_gate(p, true));
-    else hipLaunchKernelGGL(k_to_quad_planar<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, HW, make_gate(p, true));
     return hipGetLastError();
 }
 
