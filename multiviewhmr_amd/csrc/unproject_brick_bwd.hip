@@ -5,18 +5,20 @@
 // windows as the forward (brick_fwd_kernel.h) are used to sum on chip first:
 //   per brick and channel quad   re-sample the brick's voxels from the LDS-staged feature window (recompute, nothing
 //                                is saved by the forward), apply the aggregate's Jacobian (aggregate_grad), and add
-//                                ds * w into a GRADIENT window in LDS (planar per channel, so that a wave's lanes --
-//                                different window rows -- spread over the banks).  LDS float atomics run at ~190 cycles
+//                                ds * w into a GRADIENT window in LDS (planar per channel: a wave's lanes -- consecutive
+//                                z, i.e. consecutive slots of a column-major window line -- fall into consecutive
+//                                banks).  LDS float atomics run at ~190 cycles
 //                                per wave instruction on gfx950, integer ones at 4-6 (scripts/microbench_ldsatomic.hip):
 //                                the window is accumulated in FIXED POINT, one power-of-two scale per channel and quad
 //                                chosen from the block-wide max |ds| and the brick's tap multiplicity, ds_add_u32;
 //   then                         flush the gradient window: one global float atomic per window pixel and channel, issued
 //                                as 16 pixels x 4 channels = 256 contiguous bytes of the quad-planar accumulator per wave
 //                                instruction (the full-rate shape on gfx950) -- ~20 GB instead of 137 GB.
-// The accumulator is fp32 quad-planar (B,V,C/4,Hf,Wf,4), zeroed by the caller; a layout pass turns it into the caller's
-// gradient tensor.  Float atomics in the flush: run-to-run differences in the last bits (documented in the ABI).
+// Windows, staged copy and accumulator are COLUMN-major quad-planar (B,V,C/4,Wf,Hf,4) like the forward's; the accumulator is fp32,
+// zeroed by the caller; a layout pass (k_quad_planar_to_planar) turns it into the caller's planar gradient tensor.  Float atomics in
+// the flush: run-to-run differences in the last bits (documented in the ABI).
 // Autograd semantics as in the gather variant / the oracle: zero-weight taps (outside the image, z <= 0) receive nothing.
-// Measured at the north-star size: 17.1 ms (gather backward: 104 ms); DESIGN.md 5.2, profiles/r01_final_pmc.txt.
+// Measured at the north-star size: r01 17.1 ms, r02 14.0, r03 12.9 per call (gather backward: 104 ms); DESIGN.md 5.2.
 #include "brick_common.h"
 #include "kernels.h"
 
