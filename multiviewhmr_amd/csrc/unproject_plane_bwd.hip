@@ -359,6 +359,10 @@ bool plane_bwd_supported(const Problem &p)
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;   // 32-bit tap offsets into the staged copy
     if ((long long)p.B * p.V * (p.C / 4) >= (1ll << 31) || p.B > 65535) return false;
     if (p.N >= (1ll << 31) / 1024 * 1024 || p.C / 4 > 65535) return false;       // grid dimensions of the Jacobian pass
+    // a FINE grid forced onto this path (variant = gather; the gate sends fine grids to the brick kernels): a plane then sums hundreds of
+    // taps per pixel and the int32 headroom for them comes out of the resolution (one bit per doubling: 8e-6 of the largest gradient
+    // observed at 220 taps per pixel, scripts/fuzz_parity.py seed 22).  Above 32 taps per pixel on average the float scatter serves.
+    if (4 * p.N > 32ll * p.H * p.W) return false;
     if (plane_table_bytes(p) > ((size_t)4 << 30)) return false;                  // a fine grid forced onto this path: keep the old scatter
     return true;
 }

@@ -1116,8 +1116,9 @@ def test_plane_backward_vs_oracle_and_vs_the_scatter_kernel(shape, mode, gpu):
 
 
 def test_plane_backward_rescales_when_later_voxels_bring_larger_gradients(gpu):
-    """grad_out grows by 2^40 along the voxel index: every later chunk of 1024 voxels raises the running max |ds|, so the fixed-point
-    plane is shifted down again and again; the result keeps the relative precision of the LARGEST contributions"""
+    """grad_out grows by 2^40 along the voxel index: the fixed-point scale of a plane comes from the max |ds| of the whole sample (the
+    Jacobian pass's per-block maxima), so the result keeps the relative precision of the LARGEST contributions whatever the order of
+    the walk.  32 taps per pixel on average: the finest grid the plane route takes (plane_bwd_supported)"""
     shape = dict(B=1, V=4, C=4, H=32, W=32, vol=(16, 16, 32))
     feats, proj, coords = _ring_problem(seed=17, **shape)
     n = np.arange(16 * 16 * 32, dtype=np.float64).reshape(16, 16, 32)
