@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from multiviewhmr_amd import aggregation, multiview
 from oracle import cport
 ap = argparse.ArgumentParser(); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--cases", type=int, default=60)
+ap.add_argument("--dtype", default="f32", choices=("f32", "f16", "bf16"), help="f16: fp16 features and volume; bf16: fp32 features, bf16 volume / grad_out")
 a = ap.parse_args()
 gpu = torch.device("cuda:0")
 MODES = ("softmax", "sum", "mean", "max")
@@ -41,19 +42,28 @@ for case in range(a.cases):
     pts = pts @ np.array([[ct, -st, 0], [st, ct, 0], [0, 0, 1.0]]).T + centre
     coords = np.broadcast_to(pts.astype(np.float32), (B,) + pts.shape).copy()
     mode = MODES[case % 4]
+    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
+    if a.dtype == "f16": feats = torch.from_numpy(feats).half().float().numpy()   # the oracle sees the rounded inputs
     ref = cport.forward(feats, proj, coords, mode)
-    go = rng.standard_normal(ref.shape, dtype=np.float32)
+    go = torch.from_numpy(rng.standard_normal(ref.shape, dtype=np.float32)).to(tdt).float().numpy()
     gref = cport.backward(go, feats, proj, coords, mode)
+    # half-precision storage: half an ulp of the stored magnitude on top of the fp32 bar (as tests/test_unproject_gpu.py)
+    ulp = {"f32": 0.0, "f16": 2.0 ** -11, "bf16": 2.0 ** -8}[a.dtype]
+    gulp = {"f32": 0.0, "f16": 2.0 ** -10, "bf16": 0.0}[a.dtype]                 # bf16 volume: the feature gradient stays fp32
     p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
     for variant in ("auto", "brick", "gather"):
-        f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+        f = torch.from_numpy(feats).to(gpu)
+        if a.dtype == "f16": f = f.half()
+        f = f.requires_grad_(True)
         try:
-            out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant=variant)
+            out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant=variant, **({"out_dtype": torch.bfloat16} if a.dtype == "bf16" else {}))
         except (ValueError, RuntimeError) as e:
             if variant == "brick": continue                                       # shape the brick kernels do not take
             raise
-        out.backward(torch.from_numpy(go).to(gpu))
-        e1 = err(out.detach().cpu().numpy(), ref) / bound(ref); e2 = err(f.grad.cpu().numpy(), gref) / bound(gref)
+        assert out.dtype == tdt
+        out.backward(torch.from_numpy(go).to(gpu).to(tdt))
+        e1 = err(out.detach().float().cpu().numpy(), ref) / (bound(ref) + ulp * float(np.abs(ref).max()))
+        e2 = err(f.grad.float().cpu().numpy(), gref) / (bound(gref) + gulp * float(np.abs(gref).max()))
         n += 1
         if max(e1, e2) > worst:
             worst = max(e1, e2); print("case %d %s V%d C%d %dx%d vol%s %s: fwd %.3g bwd %.3g of the bound" % (case, variant, V, C, H, W, (X, Y, Z), mode, e1, e2), flush=True)
