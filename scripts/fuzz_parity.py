@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from multiviewhmr_amd import aggregation, multiview
 from oracle import cport
 ap = argparse.ArgumentParser(); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--cases", type=int, default=60)
+ap.add_argument("--big", action="store_true", help="maps of 60..220 px, volumes up to 16 x 16 x 64: windows near / beyond the LDS pool")
 ap.add_argument("--dtype", default="f32", choices=("f32", "f16", "bf16"), help="f16: fp16 features and volume; bf16: fp32 features, bf16 volume / grad_out")
 a = ap.parse_args()
 gpu = torch.device("cuda:0")
@@ -20,6 +21,10 @@ for case in range(a.cases):
     V = int(rng.choice([2, 4, 4, 8])); C = int(rng.choice([4, 8, 12, 20]))
     H, W = int(rng.integers(12, 60)), int(rng.integers(12, 60))
     X, Y, Z = int(rng.choice([4, 8, 12, 16])), int(rng.choice([8, 16])), int(rng.choice([16, 32, 64]))
+    if a.big:
+        H, W = int(rng.integers(60, 220)), int(rng.integers(60, 220))
+        X, Y, Z = int(rng.choice([8, 16])), int(rng.choice([8, 12, 16])), int(rng.choice([32, 64]))
+        C = int(rng.choice([4, 8]))
     B = int(rng.integers(1, 3))
     side = float(rng.uniform(600.0, 3000.0)); centre = rng.uniform(-300.0, 300.0, 3)
     theta = float(rng.uniform(0, 2 * np.pi)); radius = float(rng.uniform(1200.0, 6000.0)); focal = float(rng.uniform(700.0, 1800.0))
