@@ -80,7 +80,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
 
     // ---- this lane's voxel and its tap records (once per brick)
     int dcol, zin;
-    fwd_lane_voxel(lane, dcol, zin);
+    fwd_lane_voxel<0>(lane, dcol, zin);
     const int col = wave * 2 + dcol;
     const int vx = kx * kBX + (col & 3), vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
     const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_fwd_supported)

@@ -5,22 +5,25 @@
 //
 // Mapping.
 //   block   = one brick of (4 * NVOX) x (NT / 128) x 32 voxels of one sample, NT threads; a lane owns NVOX voxels (x, x+4),
-//             whose tap records (LDS address + 4 weights per view) are computed once and live in registers while the block
+//             whose tap records (two LDS addresses + 4 weights per view) are computed once and live in registers while the block
 //             loops over the C / 4 channel quads;
-//   windows = per view, the bounding box of the brick's taps; the views' windows are packed into one LDS buffer;
-//             the staged copy of the features and the LDS image are COLUMN-major quad-planar (B,V,C/4,Wf,Hf,4): a z-long
-//             brick seen by an upright camera gives tall narrow windows, so a window column is one contiguous run of the
-//             staged copy -- 26 % fewer 128-B line fills than row-major (profiles/r02_fwd_ablations.txt);
+//   windows = per view, the bounding box of the brick's taps; the views' windows are packed into one LDS buffer.  The staged copy
+//             of the features is COLUMN-major quad-planar (B,V,C/4,Wf,Hf,4): a z-long brick seen by an upright camera gives tall
+//             narrow windows, so a window column is one contiguous run of the staged copy -- 26 % fewer 128-B line fills than
+//             row-major (profiles/r02_fwd_ablations.txt).  In LDS the rows of a column are split by PARITY (MVHMR_FWD_LAY below);
 //   ring    = 2 or 3 buffers filled by LDS-DMA (global_load_lds_dwordx4).  Top of quad q: wait for this wave's DMA of quad q,
 //             s_barrier (publishes quad q; every wave has folded quad q-1, so that buffer is free), DMA of the next quad;
 //   jobs    = (quad q, voxel u): request views 0 and 1, aggregate half of the previous job, fold view 0 / request view 2,
-//             fold view 1 / request view 3, aggregate the other half + transpose + store, fold views 2 and 3 -- LDS reads,
-//             FMAs, transcendentals and the store are spread over the job;
-//   stores  = the 4 channels x 4 voxels of lanes {l, l^4, l^8, l^12} are transposed with DPP row shifts under bank masks, so
-//             that a lane QUAD writes 64 contiguous bytes of one channel: one TCP access per 4 lanes (the r01 kernel's in-quad
-//             transpose made every lane its own 16-B access: 64 per store instruction, and the CU's vector-memory pipe is
-//             what bounds this kernel).
-// Two voxels per lane (8 x 8 x 32 bricks) cut the window bytes per voxel by a third; the price is a 2-deep ring.
+//             fold view 1 / request view 3, aggregate the other half + store, fold views 2 and 3 -- LDS reads, FMAs,
+//             transcendentals (issued in runs: device_common.h aggregate2) and the stores are spread over the job;
+//   lanes   = fp32 volumes: every lane group the LDS serves in one pass of a ds_read_b128 holds 16 consecutive z of one column
+//             (conflict-free with the parity split) and a lane stores its voxel's four channels as four dwords, no transpose;
+//             16-bit volumes: the round-3 map -- the 4 channels x 4 voxels of lanes {l, l^4, l^8, l^12} are transposed with DPP
+//             row shifts under bank masks, so that a lane QUAD writes 64 contiguous bytes of one channel.
+// Two voxels per lane (8 x 8 x 32 bricks) cut the window bytes per voxel by a third.
+// Round 4 (profiles/r04_fwd_ablations.txt): the LDS side is no longer what binds (bank conflicts 692 M -> 175 M cycles, LDS busy
+// 61 % -> 36 %); what does is the CU's vector-memory pipe (LDS-DMA line fills + volume stores through one TA / TCP) on top of
+// ~2.5 ms of VALU issue.
 #pragma once
 #include "brick_common.h"
 #include "kernels.h"
@@ -29,7 +32,9 @@ namespace mvhmr {
 
 // Timing-only ablations for scripts/exp (never defined in the product build): bit 0 conflict-free fake tap addresses, 1 no tap reads,
 // 2 no LDS-DMA, 3 no stores, 4 no transcendentals, 5 no transpose, 6 no per-quad barrier, 7 no aggregate, 8 no wait for the DMA,
-// 9 LDS-DMA without the m0 save / restore, 10 phase timers of a brick (s_memtime, summed over all waves: mvhmr_exp_fwd_timers_read)
+// 9 LDS-DMA without the m0 save / restore, 10 phase timers of a brick (s_memtime, summed over all waves: mvhmr_exp_fwd_timers_read),
+// 11 stores wrapped into the first 1 MiB of the volume (they stay in L2: no HBM writes), 12 LDS-DMA sources wrapped into 128 KiB
+// (L1 / L2 hits: no miss latency)
 #ifndef MVHMR_EXP
 #define MVHMR_EXP 0
 #endif
@@ -41,11 +46,42 @@ __device__ unsigned long long g_exp_fwd_timers[8];
 #define EXP_FT(i) do { } while (0)
 #endif
 
-// lane = 32 g + 16 h + 4 a + b  ->  column h of the wave's two (x-adjacent) columns, z = 16 g + 4 b + a
+// Window layout in LDS (MVHMR_FWD_LAY): 0 = plain column-major (slot = column * stride + row); 1 = the rows of a column split by
+// PARITY: slot = column * 2 hp + (row & 1) * hp + (row >> 1), window origin row even.  A bilinear footprint {y0, y0 + 1} has one row
+// of each parity, so read instruction "even row" / "odd row" of a view fetches, for z-neighbouring lanes (1.45 px apart at the north
+// star), the same or the next half-row instead of rows up to 2 apart: the 16 lanes the LDS serves per pass of a ds_read_b128 then
+// span ~12 slots instead of ~23 and stop colliding modulo the 16 slots of a pass (scripts/sim_lds5b.py: 4.9 cycles per read
+// against 9.7; measured: profiles/r04_fwd_ablations.txt).  hp is rounded to 8 (2 hp = 0 mod 16: the pass residue does not depend on
+// the column) when the windows still fit the ring that way.
+#ifndef MVHMR_FWD_LAY
+#define MVHMR_FWD_LAY 1
+#endif
+// Lane map (MVHMR_FWD_MAP): 0 = stride-4 transpose map (lane quads 4 z apart, one 16-B store per job); 1 = every lane group of a
+// ds_read_b128 pass ({0-3,12-15,20-27}, {4-11,16-19,28-31}, +32: MI355X_MICROARCH.md, LDS) holds 16 CONSECUTIVE z of one column, no
+// transpose, four dword stores per job (a wave instruction = two 128-B runs).  16-bit volumes keep map 0 (2-B stores do not pay).
+#ifndef MVHMR_FWD_MAP
+#define MVHMR_FWD_MAP 1
+#endif
+// Rounding of hp (MVHMR_FWD_HP): 0 never, 1 always to 8, 2 to 8 when the 3-deep ring still fits, else none
+#ifndef MVHMR_FWD_HP
+#define MVHMR_FWD_HP 2
+#endif
+constexpr int kFwdLay = MVHMR_FWD_LAY, kFwdMapF32 = MVHMR_FWD_MAP, kFwdHp = MVHMR_FWD_HP;
+constexpr int kStAux = 18;         // cache policy of the volume stores: nt | sc1 (plain 3.56 ms, sc0 3.55, sc1 3.54, nt 3.44, nt sc1 3.46: r04 ablations)
+
+// map 0: lane = 32 g + 16 h + 4 a + b  ->  column h of the wave's two (x-adjacent) columns, z = 16 g + 4 b + a
+// map 1: lane = 32 h + l5; lane quads of l5 -> z quads {0, 16, 20, 4, 24, 8, 12, 28} (+ lane & 3): the LDS pass groups are z runs
+template <int MAP>
 __device__ __forceinline__ void fwd_lane_voxel(int lane, int &dcol, int &zin)
 {
-    dcol = (lane >> 4) & 1;
-    zin = ((lane >> 5) << 4) + ((lane & 3) << 2) + ((lane >> 2) & 3);
+    if constexpr (MAP == 0) {
+        dcol = (lane >> 4) & 1;
+        zin = ((lane >> 5) << 4) + ((lane & 3) << 2) + ((lane >> 2) & 3);
+    } else {
+        constexpr unsigned zq = 0u | (4u << 3) | (5u << 6) | (1u << 9) | (6u << 12) | (2u << 15) | (3u << 18) | (7u << 21);
+        dcol = lane >> 5;
+        zin = (int)(((zq >> (3 * ((lane >> 2) & 7))) & 7u) << 2) + (lane & 3);
+    }
 }
 
 // DPP move under a bank mask (bank k = lanes 4k..4k+3 of every 16-lane row): masked-off lanes keep `keep`
@@ -113,6 +149,19 @@ __device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const floa
     }
 }
 
+// s_waitcnt vmcnt(K + n) with an immediate for a wave-uniform n in 0 .. MAXI, tried from the likely end (a wave owns most of its MAXI
+// chunk slots): a handful of scalar compares instead of the 21-way switch of wait_vmcnt
+template <int K, int I, int MAXI>
+__device__ __forceinline__ void wait_vmcnt_ladder(int n)
+{
+    if constexpr (I <= 0) {
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K) : "memory");
+    } else {
+        if (n >= I) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K + I) : "memory");
+        else wait_vmcnt_ladder<K, I - 1, MAXI>(n);
+    }
+}
+
 template <int VT>
 struct FwdShared {
     int bbox[VT][4];               // xmin, ymin, xmax, ymax of the nw taps (valid voxels only)
@@ -134,6 +183,8 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int BY = NT / 128, NW = NT / 64, BXK = kBX * NVOX;
+    constexpr int MAP = sizeof(TO) == 4 ? kFwdMapF32 : 0, LAY = kFwdLay;
+    constexpr int SPJ = MAP == 1 ? 4 : 1;                                        // store instructions per job
     constexpr int MC = brick_chunks_per_wave(NT);                                 // DMA chunks a wave may own per quad
     extern __shared__ __align__(16) unsigned char smem[];
     FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + lds_slots * 16);
@@ -160,7 +211,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
 
     // ---- this lane's voxels and their tap records (once per brick)
     int dcol, zin;
-    fwd_lane_voxel(lane, dcol, zin);
+    fwd_lane_voxel<MAP>(lane, dcol, zin);
     const int col = wave * 2 + dcol;
     const int vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
     unsigned vox[NVOX];
@@ -205,25 +256,45 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     EXP_FT(1);                                                                   // barrier: block boxes complete
 
     // ---- window per view (block-uniform): origin, column stride (odd) in slots, first slot; views packed back to back
-    int wx0[VT], wy0[VT], ws[VT], nch[VT + 1], slot0[VT];
-    nch[0] = 0;
+    // LAY 1: origin row even, hp half-rows per parity, column stride 2 hp; hp rounded to 8 by policy kFwdHp
+    int wx0[VT], wy0[VT], ws[VT], whp[VT], nch[VT + 1], slot0[VT];
+    const int cap3 = fwd_cap3(lds_slots), cap2 = fwd_cap2(lds_slots);
     int used = 0, max_stride = 0;
+    auto size_windows = [&](bool round8) __attribute__((always_inline)) {
+        nch[0] = 0; used = 0; max_stride = 0;
 #pragma unroll
-    for (int v = 0; v < VT; ++v) {
-        const int xmin = uniform(sh->bbox[v][0]), ymin = uniform(sh->bbox[v][1]);
-        const int xmax = uniform(sh->bbox[v][2]), ymax = uniform(sh->bbox[v][3]);
-        int bw = 0, bh = 0;
-        if (xmax >= xmin) { bw = xmax - xmin + 2; bh = ymax - ymin + 2; }     // taps reach x0+1, y0+1
-        const int stride = bh | 1;
-        const int chunks = (stride * bw + 63) >> 6;                              // 64-slot DMA chunks
-        wx0[v] = xmin; wy0[v] = ymin; ws[v] = stride;
-        max_stride = stride > max_stride ? stride : max_stride;
-        slot0[v] = used;
-        used += chunks << 6;
-        nch[v + 1] = nch[v] + chunks;
+        for (int v = 0; v < VT; ++v) {
+            const int xmin = uniform(sh->bbox[v][0]), ymin = uniform(sh->bbox[v][1]);
+            const int xmax = uniform(sh->bbox[v][2]), ymax = uniform(sh->bbox[v][3]);
+            int bw = 0, stride = 1, hp = 0, y0w = ymin;
+            if constexpr (LAY == 0) {
+                int bh = 0;
+                if (xmax >= xmin) { bw = xmax - xmin + 2; bh = ymax - ymin + 2; }   // taps reach x0+1, y0+1
+                stride = bh | 1;
+            } else {
+                y0w = ymin & ~1;
+                if (xmax >= xmin) { bw = xmax - xmin + 2; hp = (ymax + 3 - y0w) >> 1; }   // rows y0w .. ymax + 1
+                if (round8) hp = (hp + 7) & ~7;
+                stride = 2 * hp;
+            }
+            const int chunks = (stride * bw + 63) >> 6;                          // 64-slot DMA chunks
+            wx0[v] = xmin; wy0[v] = y0w; ws[v] = stride; whp[v] = hp;
+            max_stride = stride > max_stride ? stride : max_stride;
+            slot0[v] = used;
+            used += chunks << 6;
+            nch[v + 1] = nch[v] + chunks;
+        }
+    };
+    if constexpr (LAY == 0 || kFwdHp == 0) {
+        size_windows(false);
+    } else if constexpr (kFwdHp == 1) {
+        size_windows(true);
+        if (!(used <= cap2 && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots)) size_windows(false);
+    } else {
+        size_windows(true);
+        if (!(used <= cap3 && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots)) size_windows(false);
     }
     // ring depth: 3 buffers (a DMA has between one and two iterations to land) when the windows fit a third of the pool, else 2
-    const int cap3 = fwd_cap3(lds_slots), cap2 = fwd_cap2(lds_slots);
     const int nb = used <= cap3 ? 3 : 2;
     const int cap = nb == 3 ? cap3 : cap2;
     const int buf_bytes = kZeroBytes + cap * 16;
@@ -234,89 +305,124 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     if (fits) {
         for (int i = tid; i < kZeroSlots * nb; i += NT)
             *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-        // ---- LDS byte offset (inside a buffer) of the nw tap; sw is 16 B further, ne one column stride further.  A sample that
-        // is identically zero reads the zero region at the head of the buffer (long enough for "one stride further").
-        int a0[NVOX][VT], ws16[VT];
+        // ---- LDS byte offsets (inside a buffer) of the taps in column x0; column x0 + 1 is one stride further.  A sample that is
+        // identically zero reads the zero region at the head of the buffer (long enough for "one stride further").
+        // LAY 0: a0 = the nw tap, sw 16 B further.  LAY 1: a0 = the EVEN row of the footprint, a1 = the odd row, and the weights are
+        // kept in that order (even row x0, even row x0+1, odd row x0, odd row x0+1): for an odd y0 the sum runs sw, se, nw, ne
+        // instead of ATen's nw, ne, sw, se -- one rounding order among equals (<= 1 ulp of the sample)
+        int a0[NVOX][VT], a1[LAY ? NVOX : 1][VT], ws16[VT];
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             ws16[v] = ws[v] * 16;
 #pragma unroll
             for (int u = 0; u < NVOX; ++u) {
                 const bool ok = (valid >> (u * VT + v)) & 1u;
-                const int s0 = slot0[v] + (tx[u][v] - wx0[v]) * ws[v] + (ty[u][v] - wy0[v]);
-                a0[u][v] = ok ? kZeroBytes + s0 * 16 : 0;
+                if constexpr (LAY == 0) {
+                    const int s0 = slot0[v] + (tx[u][v] - wx0[v]) * ws[v] + (ty[u][v] - wy0[v]);
+                    a0[u][v] = ok ? kZeroBytes + s0 * 16 : 0;
+                } else {
+                    const int yr = ty[u][v] - wy0[v];
+                    const int sc = slot0[v] + (tx[u][v] - wx0[v]) * ws[v];
+                    a0[u][v] = ok ? kZeroBytes + (sc + ((yr + 1) >> 1)) * 16 : 0;
+                    a1[u][v] = ok ? kZeroBytes + (sc + whp[v] + (yr >> 1)) * 16 : 0;
+                    if (yr & 1) {
+                        const float t0 = w00[u][v], t1 = w01[u][v];
+                        w00[u][v] = w10[u][v]; w01[u][v] = w11[u][v]; w10[u][v] = t0; w11[u][v] = t1;
+                    }
+                }
                 if constexpr (kExp & 1) a0[u][v] = kZeroBytes + (lane + 64 * v + 256 * u) * 16;
             }
         }
-        // ---- DMA chunks of this wave: chunk c covers 64 consecutive slots of one view's window
+        // ---- DMA chunks of this wave: chunk c covers 64 consecutive slots of one view's window; the wave owns chunks wave,
+        // wave + NW, ...: rr < n_c of its MC slots
         unsigned g_off[MC];
         int l_dst[MC];
         int n_c = 0;
 #pragma unroll
         for (int rr = 0; rr < MC; ++rr) {
             const int c = wave + rr * NW;
-            l_dst[rr] = -1;
+            l_dst[rr] = 0;
             g_off[rr] = 0;
             if (c < nch[VT]) {
                 int v = 0;
 #pragma unroll
                 for (int uu = 1; uu < VT; ++uu) v += c >= nch[uu] ? 1 : 0;
-                int sv = ws[0], ox = wx0[0], oy = wy0[0], c0 = nch[0], s0 = slot0[0];
+                int sv = ws[0], ox = wx0[0], oy = wy0[0], c0 = nch[0], s0 = slot0[0], hv = whp[0];
 #pragma unroll
-                for (int uu = 1; uu < VT; ++uu) if (v == uu) { sv = ws[uu]; ox = wx0[uu]; oy = wy0[uu]; c0 = nch[uu]; s0 = slot0[uu]; }
+                for (int uu = 1; uu < VT; ++uu) if (v == uu) { sv = ws[uu]; ox = wx0[uu]; oy = wy0[uu]; c0 = nch[uu]; s0 = slot0[uu]; hv = whp[uu]; }
                 const int jj = c - c0, slot = (jj << 6) + lane;
-                const int px = slot / sv, py = slot - px * sv;
-                int gx = ox + px, gy = oy + py;                                  // pad row / columns past the window / outside the
+                const int px = slot / sv;
+                int py = slot - px * sv;
+                if constexpr (LAY == 1) py = py >= hv ? 2 * (py - hv) + 1 : 2 * py;   // slot inside the column -> row
+                int gx = ox + px, gy = oy + py;                                  // pad rows / columns past the window / outside the
                 gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);                     // image: clamp -- those slots only meet zero weights
                 gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
                 g_off[rr] = (unsigned)((v * nq) * HW + gx * H + gy) * 16u;
-                l_dst[rr] = kZeroBytes + (s0 + (jj << 6)) * 16;
+                if constexpr (kExp & 4096) g_off[rr] &= 0x1FFF0u;
+                l_dst[rr] = uniform(kZeroBytes + (s0 + (jj << 6)) * 16) + (int)(unsigned)(size_t)(lds_void_t *)smem;
                 ++n_c;
             }
         }
-        const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
-        auto ring = [&](int q) __attribute__((always_inline)) { return (nb == 3 ? q % 3 : q & 1) * buf_bytes; };
-        auto dma = [&](int q) __attribute__((always_inline)) {
-            const float4 *src = fk + (long long)q * HW;
-            const int boff = ring(q);
+        // What changes per quad is carried in scalar registers: the ring offsets of quads q, q+1, q+2 (rotated, no q % 3), the plane
+        // of the staged copy the next request reads (one pointer add), this quad's and the previous quad's store descriptors.
+        int r0 = 0, r1 = buf_bytes, r2 = 2 * buf_bytes;
+        const float4 *src_n = fk;                                                // plane of the next quad to request
+        auto dma = [&](int roff) __attribute__((always_inline)) {
 #pragma unroll
             for (int rr = 0; rr < MC; ++rr)
-                if (l_dst[rr] >= 0 && !(kExp & 4)) {
-                    if constexpr (kExp & 512) glds16_m0(src, g_off[rr], lds_base + (unsigned)uniform(l_dst[rr] + boff));
-                    else glds16(src, g_off[rr], lds_base + (unsigned)uniform(l_dst[rr] + boff));
-                }
+                if (rr < n_c && !(kExp & 4)) glds16_m0(src_n, g_off[rr], (unsigned)(l_dst[rr] + roff));
+            src_n += HW;
         };
 
-        // ---- stores: lane 4a+b (+16h+32g) writes channel a, z = 16g + 4b .. 4b+3 of its column
+        // ---- stores.  Map 1: the lane's own voxel, channel i at soffset i * chan_bytes (a wave instruction = two 128-B runs of one
+        // channel plane; the TA coalesces it in 4 cycles: TA_BUFFER_COALESCED_WRITE_CYCLES).  Map 0: lane 4a+b (+16h+32g) writes
+        // channel a, z = 16g + 4b .. 4b+3 of its column after the stride-4 transpose.
         constexpr unsigned OSZ = sizeof(TO);
         const unsigned chan_bytes = (unsigned)(N * OSZ);
         unsigned st_off[NVOX];
 #pragma unroll
         for (int u = 0; u < NVOX; ++u) {
-            const int z0 = ((lane >> 5) << 4) + ((lane & 3) << 2);
-            st_off[u] = (vox[u] - (unsigned)zin + (unsigned)z0) * OSZ + (unsigned)((lane >> 2) & 3) * chan_bytes;
-        }
-        auto store_quad = [&](int q, int u, float (&res)[4]) __attribute__((always_inline)) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
-            if constexpr (!(kExp & 32)) stride4_transpose(res, lane);
-            if constexpr (kExp & 8) {
-                asm volatile("" :: "v"(res[0]), "v"(res[1]), "v"(res[2]), "v"(res[3]), "s"(rs));
-            } else if constexpr (OSZ == 4) {
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
-                                 __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off[u], 0, 18);   // nt sc1: best of the five policies (r02 ablations)
+            if constexpr (MAP == 1) {
+                st_off[u] = vox[u] * OSZ;
+                if constexpr (kExp & 2048) st_off[u] &= 0x3FFFFu;
             } else {
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                const u32x2 d = {pack2<TO>(res[0], res[1]), pack2<TO>(res[2], res[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)st_off[u], 0, 18);
+                const int z0 = ((lane >> 5) << 4) + ((lane & 3) << 2);
+                st_off[u] = (vox[u] - (unsigned)zin + (unsigned)z0) * OSZ + (unsigned)((lane >> 2) & 3) * chan_bytes;
+            }
+        }
+        auto make_rs = [&](TO *base) __attribute__((always_inline)) {
+            return __builtin_amdgcn_make_buffer_rsrc((kExp & 2048) ? out : base, 0, (int)(4u * chan_bytes), 0x00020000);
+        };
+        auto store_quad = [&](const __amdgpu_buffer_rsrc_t rs, int u, float (&res)[4]) __attribute__((always_inline)) {
+            if constexpr (MAP == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if constexpr (kExp & 8) asm volatile("" :: "v"(res[i]), "s"(rs));
+                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rs, (int)st_off[u],
+                                                               (kExp & 2048) ? i * 0x40000 : (int)(i * chan_bytes), (kExp & 2048) ? 0 : kStAux);
+                }
+            } else {
+                if constexpr (!(kExp & 32)) stride4_transpose(res, lane);
+                if constexpr (kExp & 8) {
+                    asm volatile("" :: "v"(res[0]), "v"(res[1]), "v"(res[2]), "v"(res[3]), "s"(rs));
+                } else if constexpr (OSZ == 4) {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
+                                     __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off[u], 0, kStAux);
+                } else {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    const u32x2 d = {pack2<TO>(res[0], res[1]), pack2<TO>(res[2], res[3])};
+                    __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)st_off[u], 0, kStAux);
+                }
             }
         };
 
-        // ---- taps: two register sets of 4 x b128 (nw, ne, sw, se), used alternately by consecutive views
+        // ---- taps: two register sets of 4 x b128 (LAY 0: nw, ne, sw, se; LAY 1: even row x0 / x0+1, odd row x0 / x0+1), used
+        // alternately by consecutive views
         f32x4 T[2][4];
-        auto read_view = [&](int q, int u, int v, int set) __attribute__((always_inline)) {
-            const int base = a0[u][v] + ring(q), far = base + ws16[v];
+        auto read_view = [&](int roff, int u, int v, int set) __attribute__((always_inline)) {
+            const int base = a0[u][v] + roff, far = base + ws16[v];
             if constexpr (kExp & 2) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -324,8 +430,14 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                     for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(T[set][t].v[i]) : "v"(base), "v"(far));
                 return;
             }
-            T[set][0] = lds_tap(smem, base); T[set][2] = lds_tap(smem, base + 16);
-            T[set][1] = lds_tap(smem, far); T[set][3] = lds_tap(smem, far + 16);
+            if constexpr (LAY == 0) {
+                T[set][0] = lds_tap(smem, base); T[set][2] = lds_tap(smem, base + 16);
+                T[set][1] = lds_tap(smem, far); T[set][3] = lds_tap(smem, far + 16);
+            } else {
+                const int base1 = a1[u][v] + roff, far1 = base1 + ws16[v];
+                T[set][0] = lds_tap(smem, base); T[set][2] = lds_tap(smem, base1);
+                T[set][1] = lds_tap(smem, far); T[set][3] = lds_tap(smem, far1);
+            }
         };
         float sq[4][VT], sp[4][VT], res[4];
 #pragma unroll
@@ -336,32 +448,44 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
 #pragma unroll
             for (int v = 0; v < VT; ++v) { sq[i][v] = 0.f; sp[i][v] = 0.f; }
         }
-        for (int q = 0; q < nb - 1 && q < nq; ++q) dma(q);
+        dma(0);                                                                  // quad 0 -> buffer 0
+        if (nb == 3 && nq > 1) dma(r1);                                          // quad 1 -> buffer 1
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the zero regions are written
         EXP_FT(2);                                                               // windows, addresses, chunk table, first DMA issued
-        const int a_step = wave & (VT - 1);
-        // counted wait at the top of quad q: the DMA of quad q must have landed; at least NVOX stores (and, with three buffers,
-        // the n_c DMAs of quad q+1) of this wave are younger.  The first and the last iterations lack part of that order.
-        const int ncw = nb == 2 ? NVOX : NVOX + n_c;
+        __amdgpu_buffer_rsrc_t rs_cur = make_rs(obase), rs_prev = rs_cur;
+        TO *oq_cur = obase;
+        const long long qstride = 4 * N;                                         // elements between the channel planes of consecutive quads
 
-        // PAR: which of sq / sp receives the samples of job u = 0 (alternates per quad when NVOX is odd)
+        // One quad.  Top: counted wait for this wave's DMA of quad q, s_barrier (publishes quad q; every wave has folded quad q-1, so
+        // that buffer is free); two buffers: request quad q+1 here.  Jobs (quad q, voxel u): request views 0 and 1, aggregate half of
+        // the PREVIOUS job, fold view 0 / request view 2, fold view 1 / request view 3 (three buffers: behind it, in the first job,
+        // the LDS-DMA of quad q+2 -- ONE site per quad), aggregate the other half + store, fold views 2 and 3.
+        // PAR: which of sq / sp receives the samples of job u = 0 (alternates per quad when NVOX is odd).
+        // The counted wait: the DMA of quad q must have landed; younger than it are the stores of NVOX jobs (two buffers) or of
+        // 2 NVOX - 1 jobs plus the n_c pieces of quad q+1 (three buffers).  The first and the last iterations lack part of that order.
+        constexpr int DMA_V = VT > 1 ? 1 : 0;
         auto quad_iter = [&](int q, auto par_tag) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value;
-            if constexpr (!(kExp & 256)) { if (q < 2 || q + 1 >= nq) wait_vmcnt(0); else wait_vmcnt(ncw); }
+            if constexpr (!(kExp & 256)) {
+                constexpr int K2 = NVOX * SPJ, K3 = (2 * NVOX - 1) * SPJ;
+                static_assert(K3 + MC <= 63, "vmcnt is a 6-bit field");
+                if (q < 2 || q + 1 >= nq) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (nb == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K2) : "memory");
+                else wait_vmcnt_ladder<K3, MC, MC>(n_c);
+            }
             if constexpr (!(kExp & 64)) bare_barrier();
 #if MVHMR_EXP & 1024
             if (q == 0) EXP_FT(3);                                               // window 0 landed + barrier
 #endif
-            if (nb == 2 && q + 1 < nq) dma(q + 1);
+            if (nb == 2 && q + 1 < nq) dma(r1);
 #pragma unroll
             for (int u = 0; u < NVOX; ++u) {
                 // this job's samples go to sq / sp alternately; the previous job's are aggregated in two halves between the folds
                 // (the live samples stay 16 registers: rows of `prev` die as columns of `cur` are born)
                 auto &cur = ((u + PAR) & 1) ? sp : sq;
                 auto &prev = ((u + PAR) & 1) ? sq : sp;
-                const bool st = q > 0 || u > 0;
-                read_view(q, u, 0, 0);
-                if constexpr (VT > 1) read_view(q, u, 1, 1);
+                read_view(r0, u, 0, 0);
+                if constexpr (VT > 1) read_view(r0, u, 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 fwd_aggregate2<METHOD, VT>(prev[0], prev[1], res[0], res[1]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -369,7 +493,8 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 for (int v = 0; v < VT; ++v) {
                     if (v == (VT + 1) / 2) {
                         fwd_aggregate2<METHOD, VT>(prev[2], prev[3], res[2], res[3]);
-                        if (st) store_quad(u > 0 ? q : q - 1, u > 0 ? u - 1 : NVOX - 1, res);
+                        if (u > 0) store_quad(rs_cur, u - 1, res);
+                        else if (q > 0) store_quad(rs_prev, NVOX - 1, res);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -378,11 +503,17 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                         asm volatile("" : "+v"(cur[i][v]));                       // fold HERE: keeps the tap registers short-lived
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (v + 2 < VT) read_view(q, u, v + 2, v & 1);
-                    if (nb == 3 && u == 0 && a_step == v && q + 2 < nq) dma(q + 2);   // the block's waves spread their DMAs over the job
+                    if (v + 2 < VT) read_view(r0, u, v + 2, v & 1);
+                    if (u == 0 && v == DMA_V && nb == 3 && q + 2 < nq) dma(r2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            // next quad: rotate the ring offsets, advance the store descriptors
+            const int t0 = r0;
+            r0 = r1; r1 = nb == 3 ? r2 : t0; r2 = t0;
+            rs_prev = rs_cur;
+            oq_cur += qstride;
+            rs_cur = make_rs(oq_cur);
         };
         if constexpr (NVOX & 1) {
             for (int q = 0; q < nq; q += 2) {
@@ -392,14 +523,14 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         } else {
             for (int q = 0; q < nq; ++q) quad_iter(q, std::integral_constant<int, 0>{});
         }
-        // the last job: (nq - 1, NVOX - 1)
+        // the last job: (nq - 1, NVOX - 1); rs_prev is the descriptor of quad nq - 1 by now
         const bool last_in_sp = ((NVOX & 1) ? nq - 1 : NVOX - 1) & 1;
 #pragma unroll
         for (int c = 0; c < 4; c += 2) {
             if (last_in_sp) fwd_aggregate2<METHOD, VT>(sp[c], sp[c + 1], res[c], res[c + 1]);
             else fwd_aggregate2<METHOD, VT>(sq[c], sq[c + 1], res[c], res[c + 1]);
         }
-        store_quad(nq - 1, NVOX - 1, res);
+        store_quad(rs_prev, NVOX - 1, res);
         EXP_FT(4);                                                               // the quad loop
 #if MVHMR_EXP & 1024
         if (lane == 0) {

@@ -169,10 +169,43 @@ __device__ __forceinline__ float aggregate(const float (&s)[V])
 // One class test on  den_a * den_b + (r_a + r_b)  therefore catches every such case of either channel (Inf - Inf reads NaN: still
 // caught; den_a * den_b >= 2^128 with both quotients fine is a false alarm, only slow), and the wave redoes both channels in the
 // max form -- a wave-uniform branch.  Underflow is harmless: e_v -> 0 is the limit of the weight.
+// Issue order (MVHMR_AGG_GROUP, default 1): the transcendentals of both channels are issued BACK TO BACK -- 2 (V - 1) v_exp_f32,
+// later the two v_rcp_f32 -- instead of wherever the scheduler drops them among the subtractions and fmas: on gfx950 a v_exp_f32
+// between plain VALU instructions costs ~2 ns more than in a run of its kind (scripts/microbench_trans.hip: 4 exp + 12 fma per
+// iteration take 31.3 ns grouped, 38.9 ns as exp, fma, fma, fma; the sum of the parts is 29.2).  Same operations, same results.
+#ifndef MVHMR_AGG_GROUP
+#define MVHMR_AGG_GROUP 1
+#endif
 template <int METHOD, int V>
 __device__ __forceinline__ void aggregate2(const float (&sa)[V], const float (&sb)[V], float &ra, float &rb)
 {
-    if constexpr (METHOD == AGG_SOFTMAX && V > 1) {
+    if constexpr (METHOD == AGG_SOFTMAX && V > 1 && MVHMR_AGG_GROUP) {
+        float ta[V], tb[V];
+#pragma unroll
+        for (int v = 1; v < V; ++v) {
+            ta[v] = (sa[v] - sa[0]) * 1.4426950408889634f;
+            tb[v] = (sb[v] - sb[0]) * 1.4426950408889634f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 1; v < V; ++v) { ta[v] = __builtin_amdgcn_exp2f(ta[v]); tb[v] = __builtin_amdgcn_exp2f(tb[v]); }
+        __builtin_amdgcn_sched_barrier(0);
+        float da = 1.f, db = 1.f, na = sa[0], nb = sb[0];
+#pragma unroll
+        for (int v = 1; v < V; ++v) {
+            da += ta[v]; na = fmaf(ta[v], sa[v], na);
+            db += tb[v]; nb = fmaf(tb[v], sb[v], nb);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const float ia = __builtin_amdgcn_rcpf(da), ib = __builtin_amdgcn_rcpf(db);
+        __builtin_amdgcn_sched_barrier(0);
+        ra = na * ia;
+        rb = nb * ib;
+        if (__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(fmaf(da, db, ra + rb)) < __builtin_inff())) != 0) {
+            ra = aggregate<METHOD, V>(sa);
+            rb = aggregate<METHOD, V>(sb);
+        }
+    } else if constexpr (METHOD == AGG_SOFTMAX && V > 1) {
         auto one = [](const float (&s)[V], float &den) __attribute__((always_inline)) {
             float num = s[0];
             den = 1.f;

@@ -72,6 +72,7 @@ struct GateGeom {
     int bx, by, bz;      // brick extent in voxels
     int view_group;      // views whose windows are resident together (0: all of them)
     int column_major;    // window lines run along y (forward) or x (backward)
+    int parity_rows;     // forward: the rows of a window column are split by parity (line stride 2 * ceil(rows / 2), origin row even)
     int cap_slots;       // 16-B LDS slots one window set may use
     int max_chunks;      // 64-slot DMA chunks a block can issue per quad
 };

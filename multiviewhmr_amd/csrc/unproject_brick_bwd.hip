@@ -648,7 +648,7 @@ GateGeom brick_bwd_gate_geom(const Problem &p)
     const int nt = p.V == 8 ? kNTb8 : kNTb;
     GateGeom g;
     g.bz = bwd_brick_z(p);
-    g.bx = bwd_brick_x(g.bz); g.by = nt / (g.bz * g.bx); g.column_major = 1; g.view_group = 0;
+    g.bx = bwd_brick_x(g.bz); g.by = nt / (g.bz * g.bx); g.column_major = 1; g.view_group = 0; g.parity_rows = 0;
     g.cap_slots = bwd_cap_slots(nt, g.bz);
     g.max_chunks = brick_chunks_per_wave(nt) * (nt / 64);
     return g;

@@ -130,6 +130,7 @@ GateGeom brick_fwd_gate_geom(const Problem &p)
     const int nt = brick_fwd_grouped(p) ? 1024 : fwd_threads(p.V);
     GateGeom g;
     g.bx = kBX * brick_fwd_nvox(p); g.by = nt / 128; g.bz = kBZ; g.column_major = 1;
+    g.parity_rows = (!brick_fwd_grouped(p) && kFwdLay == 1) ? 1 : 0;
     g.view_group = brick_fwd_grouped(p) ? 4 : 0;
     g.cap_slots = fwd_cap2(fwd_lds_slots());                              // the 2-deep ring still stages through LDS
     g.max_chunks = brick_fwd_grouped(p) ? 4 * (nt / 64) : brick_chunks_per_wave(nt) * (nt / 64);
@@ -173,7 +174,12 @@ k_brick_gate(const float *__restrict__ proj, const Coords coords, int *__restric
         const float y0 = fmaxf(floorf(ymin), -1.f), y1 = fminf(floorf(ymax), (float)(H - 1));
         if (x1 < x0 || y1 < y0) continue;                                        // wholly outside the image
         const int bw = (int)(x1 - x0) + 2, bh = (int)(y1 - y0) + 2;
-        const int stride = (g.column_major ? bh : bw) | 1, lines = g.column_major ? bw : bh;
+        int stride = (g.column_major ? bh : bw) | 1;
+        const int lines = g.column_major ? bw : bh;
+        if (g.parity_rows) {                                                     // the forward's parity-split columns: origin row even, 2 hp slots
+            const int y0e = (int)y0 & ~1;
+            stride = 2 * (((int)y1 + 3 - y0e) >> 1);
+        }
         const int chunks = (stride * lines + 63) >> 6;
         used += chunks << 6;
         chunks_all += chunks;
