@@ -374,6 +374,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             src_n += HW;
         };
 
+
         // ---- stores.  Map 1: the lane's own voxel, channel i at soffset i * chan_bytes (a wave instruction = two 128-B runs of one
         // channel plane; the TA coalesces it in 4 cycles: TA_BUFFER_COALESCED_WRITE_CYCLES).  Map 0: lane 4a+b (+16h+32g) writes
         // channel a, z = 16g + 4b .. 4b+3 of its column after the stride-4 transpose.
@@ -463,11 +464,15 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // PAR: which of sq / sp receives the samples of job u = 0 (alternates per quad when NVOX is odd).
         // The counted wait: the DMA of quad q must have landed; younger than it are the stores of NVOX jobs (two buffers) or of
         // 2 NVOX - 1 jobs plus the n_c pieces of quad q+1 (three buffers).  The first and the last iterations lack part of that order.
-        constexpr int DMA_V = VT > 1 ? 1 : 0;
+        // the DMA site: first job, behind the fold of the view whose head carries the stores -- a request burst in FRONT of the
+        // stores holds them up in the TA / TCP (site behind fold 1: 3.41 ms, behind fold 2 or 3: 3.34; pieces or stores spread over
+        // the job: 3.39-3.62: profiles/r04_fwd_ablations.txt)
+        constexpr int DMA_U = 0, DMA_V = (VT + 1) / 2 < VT ? (VT + 1) / 2 : VT - 1;
         auto quad_iter = [&](int q, auto par_tag) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value;
             if constexpr (!(kExp & 256)) {
-                constexpr int K2 = NVOX * SPJ, K3 = (2 * NVOX - 1) * SPJ;
+                // three buffers: store groups behind the DMA site in its own quad + everything of the next quad
+                constexpr int K2 = NVOX * SPJ, K3 = (NVOX - DMA_U - (DMA_V >= (VT + 1) / 2 ? 1 : 0)) * SPJ + NVOX * SPJ;
                 static_assert(K3 + MC <= 63, "vmcnt is a 6-bit field");
                 if (q < 2 || q + 1 >= nq) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 else if (nb == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K2) : "memory");
@@ -504,7 +509,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (v + 2 < VT) read_view(r0, u, v + 2, v & 1);
-                    if (u == 0 && v == DMA_V && nb == 3 && q + 2 < nq) dma(r2);
+                    if (u == DMA_U && v == DMA_V && nb == 3 && q + 2 < nq) dma(r2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
