@@ -116,12 +116,18 @@ int variant_conflict(const mvhmr_unproject_desc *d, const Problem &p, int varian
 // the gradient can be accumulated straight into grad_features when that already is fp32 channels-last
 bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->feat_layout == MVHMR_LAYOUT_BVHWC && !p.feat_f16; }
 
+constexpr int kChipCUs = 256;       // MI355X
+
 // The brick backward (window gradients accumulated in LDS in fixed point, then flushed with 256-B shaped float atomics)
 // is the default wherever the brick forward is: ~20 GB of global atomic traffic instead of the gather backward's 137 GB
 // (17 ms against 104 ms at the north-star size: profiles/r01_final_pmc.txt).  variant = gather keeps the gather backward.
 bool bwd_uses_brick(const mvhmr_unproject_desc *d, const Problem &p)
 {
     if (d->feat_layout == MVHMR_LAYOUT_QUAD && p.feat_f16) return false;        // the quad copy is fp32; mixed storage goes through the gather backward
+    // A volume of fewer bricks than the chip has CUs (the reference's shipped 16^3: 4 bricks per sample) leaves most of it idle while every
+    // block still walks all C / 4 quads: 0.48 ms for 32 samples of 16^3 against 0.2x for the plane kernels, whose blocks are (sample,
+    // view, quad).  AUTO then takes the plane backward; variant = brick still forces the bricks.
+    if (d->variant == MVHMR_VARIANT_AUTO && plane_bwd_supported(p) && brick_bwd_supported(p) && brick_count(p, brick_bwd_gate_geom(p)) < kChipCUs) return false;
     return (d->feat_layout == MVHMR_LAYOUT_BVCHW || d->feat_layout == MVHMR_LAYOUT_QUAD) && d->variant != MVHMR_VARIANT_GATHER && brick_bwd_supported(p);
 }
 

@@ -19,10 +19,17 @@
 //   and the vector L1 was what bound it -- 1.48 ms for configs[1] against 0.3 + 0.2 ms for the two passes.)
 //
 //   plane       planar per channel, row stride Wf | 1 (a z column's taps are Wf-strided rows: an odd stride spreads them over the
-//               banks), int32 FIXED POINT: ds_add_f32 costs ~190 cycles per wave instruction on gfx950, ds_add_u32 4-6.  One scale
-//               per channel, fixed BEFORE the walk from the exact max |ds| of the block's stream (a first pass over it) times the
-//               plane's tap multiplicity: no sum can overflow, and the walk needs neither a block-wide reduction nor a barrier -- the
-//               waves drift apart.  Resolution: 2^-31 * multiplicity of that bound per contribution;
+//               banks), FIXED POINT: ds_add_f32 costs ~190 cycles per wave instruction on gfx950, ds_add_u32 4-6, ds_add_u64 ~8.
+//               One scale per (view, channel), fixed BEFORE the walk from the exact max |ds| of that view's stream (the Jacobian pass
+//               leaves it), so the walk needs neither a block-wide reduction nor a barrier -- the waves drift apart.  Three forms:
+//                 int32 x 4 channels   the contributions are scaled to (2^31 - 2^23) / (multiplicity * max |ds|): no sum can overflow;
+//                                      resolution 2^-31 * multiplicity of the view's largest |ds| per contribution.  Planes whose most
+//                                      hit pixel receives <= kWideTaps taps;
+//                 int64 x 2 channels   two walks over the stream, two channels each, in the same LDS bytes: contributions scaled to
+//                                      the full int32 range, SUMS kept in 64 bits -- the resolution (2^-31 of the view's largest |ds|)
+//                                      no longer depends on how many taps meet in a pixel.  Planes above kWideTaps (a far or zoomed-out
+//                                      camera, a fine grid over a coarse map), and bounds that overflow fp32;
+//                 int64 x 4 channels   the same in one walk, for maps small enough for 8-B cells (<= ~68 x 68): always;
 //   non-finite  an Inf / NaN contribution cannot be carried in fixed point: its pixels are marked in a bit plane and written as NaN
 //               -- exactly the pixels the reference's float scatter poisons (the gather variant's contract).
 // Features are read from the column-major quad-planar fp32 copy (MVHMR_LAYOUT_QUAD: a tap = one 16-B load of 4 channels).
@@ -41,11 +48,13 @@ struct PlaneShared {
 };
 
 __host__ __device__ inline int plane_row_stride(int W) { return W | 1; }
-__host__ __device__ inline size_t plane_lds_bytes(int H, int W)
+__host__ __device__ inline size_t plane_lds_bytes(int H, int W, int cell_bytes = 4)
 {
     const size_t cells = (size_t)H * plane_row_stride(W);
-    return 4 * cells * sizeof(int) + 4 * ((cells + 31) / 32) * sizeof(int) + sizeof(PlaneShared);
+    return 4 * cells * cell_bytes + 4 * ((cells + 31) / 32) * sizeof(int) + sizeof(PlaneShared);
 }
+// maps small enough for 8-byte cells of all four channels
+__host__ __device__ inline bool plane_wide4(int H, int W) { return plane_lds_bytes(H, W, 8) <= (size_t)kPlaneLdsBytes; }
 
 // ------------------------------------------------------------------------------------------------- tap table
 // One block per (sample, view): weights + packed clamped tap coordinates of every voxel, and the most taps any pixel of the plane
@@ -161,35 +170,43 @@ k_plane_ds(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, co
 #pragma unroll
         for (int v = 0; v < VT; ++v) dst[(long long)v * nq * N] = make_float4(ds[0][v], ds[1][v], ds[2][v], ds[3][v]);   // plain store: the plane kernel reads it next
     }
-    // ---- max |ds| per channel over this block's voxels and all views (finite values only: the plane kernel marks the others), for the
-    // fixed-point scale.  Non-negative floats order as their bit patterns.  One int4 per block, no atomics: the plane blocks take the
-    // max over their sample's and quad's entries.
-    __shared__ int wmax[kDsThreads / 64][4];
+    // ---- max |ds| per (view, channel) over this block's voxels (finite values only: the plane kernel marks the others), for the
+    // fixed-point scales -- per VIEW: a view whose gradients are small next to another view's keeps its own resolution.  Non-negative
+    // floats order as their bit patterns.  One int4 per (block, view), no atomics: the plane blocks take the max over their sample's,
+    // view's and quad's entries.
+    __shared__ int wmax[kDsThreads / 64][VT][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int m = 0;
+    for (int v = 0; v < VT; ++v)
 #pragma unroll
-        for (int v = 0; v < VT; ++v) {
+        for (int i = 0; i < 4; ++i) {
             const int bits = __builtin_bit_cast(int, ds[i][v]) & 0x7fffffff;
-            m = bits < 0x7f800000 && bits > m ? bits : m;
+            const int m = wave_max_to_last_row(bits < 0x7f800000 ? bits : 0);
+            if ((threadIdx.x & 63) == 63) wmax[threadIdx.x >> 6][v][i] = m;
         }
-        m = wave_max_to_last_row(m);
-        if ((threadIdx.x & 63) == 63) wmax[threadIdx.x >> 6][i] = m;
-    }
     __syncthreads();
-    if (threadIdx.x < 4) {
-        int m = wmax[0][threadIdx.x];
+    if (threadIdx.x < VT * 4) {
+        const int v = threadIdx.x >> 2, i = threadIdx.x & 3;
+        int m = wmax[0][v][i];
 #pragma unroll
-        for (int w = 1; w < kDsThreads / 64; ++w) m = wmax[w][threadIdx.x] > m ? wmax[w][threadIdx.x] : m;
-        dsMax[(((long long)b * nq + q) * gridDim.x + blockIdx.x) * 4 + threadIdx.x] = m;
+        for (int w = 1; w < kDsThreads / 64; ++w) m = wmax[w][v][i] > m ? wmax[w][v][i] : m;
+        dsMax[((((long long)b * nq + q) * VT + v) * gridDim.x + blockIdx.x) * 4 + i] = m;
     }
 }
 
 // ------------------------------------------------------------------------------------------------- the plane kernel
 // One block per (sample, view, channel quad): reads its ds stream and its view's tap table (36 B per voxel, coalesced), adds the four
-// taps of every voxel into the LDS plane, writes the plane once.  The fixed-point scale is fixed BEFORE the walk from the max |ds| of
-// the sample's channel (all views: the Jacobian pass leaves one int4 per block) and the plane's tap multiplicity.
-template <typename TF>
+// taps of every voxel into the LDS plane, writes the plane once.  The fixed-point scales are fixed BEFORE the walk from the max |ds| of
+// the sample's (view, channel) -- the Jacobian pass leaves one int4 per block and view -- and, in the int32 form, the plane's tap
+// multiplicity.  WIDE4: 8-byte cells for all four channels (small maps); otherwise the block picks int32 x 4 channels or, for planes
+// whose most hit pixel receives more than kWideTaps taps, int64 x 2 channels in two walks (the same LDS bytes).
+constexpr int kWideTaps = 64;          // int32 form: resolution 2^-31 * taps of the view's max |ds| per contribution -> <= 3e-8 of it
+
+__device__ __forceinline__ void lds_add64(long long *p, int v)
+{
+    __hip_atomic_fetch_add(p, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <typename TF, bool WIDE4>
 __global__ void __launch_bounds__(1024)
 k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int ds_blocks, const float4 *__restrict__ tabW,
             const int *__restrict__ tabX, const int *__restrict__ cmax, TF *__restrict__ grad_features, int C, int V, int H, int W, long long N,
@@ -199,101 +216,138 @@ k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int d
     constexpr int kPlaneThreads = 1024;
     extern __shared__ __align__(16) unsigned char smem[];
     const int Ws = plane_row_stride(W), cells = H * Ws, mask_words = (cells + 31) >> 5;
-    int *const planes = reinterpret_cast<int *>(smem);                           // [4][cells]
-    unsigned *const poison = reinterpret_cast<unsigned *>(planes + 4 * cells);   // [4][mask_words]
+    constexpr int CELL = WIDE4 ? 8 : 4;                                          // bytes per cell of the four-channel image
+    int *const planes = reinterpret_cast<int *>(smem);                           // [4][cells] int32, [2][cells] / [4][cells] int64
+    unsigned *const poison = reinterpret_cast<unsigned *>(smem + (size_t)4 * cells * CELL);   // [4][mask_words]
     PlaneShared *const sh = reinterpret_cast<PlaneShared *>(poison + 4 * mask_words);
     const int tid = threadIdx.x;
     const int nq = C >> 2, HW = H * W;
     const int q = blockIdx.x % nq, v_own = (blockIdx.x / nq) % V, b = blockIdx.x / (nq * V);
+    const int plane_words = 4 * cells * (CELL / 4);
 
-    for (int i = tid; i < 4 * cells + 4 * mask_words; i += kPlaneThreads) planes[i] = 0;      // the bit planes follow the planes
+    for (int i = tid; i < plane_words + 4 * mask_words; i += kPlaneThreads) planes[i] = 0;    // the bit planes follow the planes
     if (tid < 4) sh->gmax[tid] = 0;
     __syncthreads();
 
     const float4 *const dq = dsW + (((long long)b * V + v_own) * nq + q) * N;
     const float4 *const tw = tabW + ((long long)b * V + v_own) * N;
     const int *const tx = tabX + ((long long)b * V + v_own) * N;
-    // ---- max |ds| per channel over the sample's voxels (all views: the Jacobian pass's per-block maxima)
+    // ---- max |ds| per channel over the sample's voxels, THIS view (the Jacobian pass's per-block maxima)
     {
-        const int *const mq = dsMax + ((long long)b * nq + q) * ds_blocks * 4;
+        const int *const mq = dsMax + (((long long)b * nq + q) * V + v_own) * ds_blocks * 4;
         int gm = 0;
         for (int k = tid >> 2; k < ds_blocks; k += kPlaneThreads >> 2) { const int m = mq[k * 4 + (tid & 3)]; gm = m > gm ? m : gm; }
         if (gm) atomicMax(&sh->gmax[tid & 3], gm);
     }
     __syncthreads();
-    // scale per channel: every contribution is at most gmax (weights <= 1), at most `cm` of them meet in one pixel, so with
-    // scale = (2^31 - 2^23) / (cm * gmax) no sum leaves int32 -- and nothing of the 31 bits is given away to a power-of-two rounding
     const int cm = uniform(cmax[b * V + v_own]);
-    float scale[4], inv_scale[4];                                                 // 0: every finite ds of this channel is zero
-    bool over[4];                                                                 // the bound itself overflows fp32: nothing can be scaled
+    float gm[4];
+    bool int32_ok = !WIDE4 && cm <= kWideTaps;                                    // block-uniform
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float full = (float)cm * __builtin_bit_cast(float, uniform(sh->gmax[i]));
-        const bool ok = full > 0.f && full < 3.0e38f;
-        over[i] = !(full < 3.0e38f);                                              // (inf included): non-zero contributions become NaN pixels
+        gm[i] = __builtin_bit_cast(float, uniform(sh->gmax[i]));
+        if (!((float)cm * gm[i] < 3.0e38f)) int32_ok = false;                     // the int32 bound itself overflows fp32: the wide form carries it
+    }
+    // scale per channel.  int32 form: every contribution is at most gmax (weights <= 1), at most `cm` of them meet in one pixel, so with
+    // scale = (2^31 - 2^23) / (cm * gmax) no sum leaves int32 -- nothing of the 31 bits is given away to a power-of-two rounding.
+    // int64 forms: scale = (2^31 - 2^23) / gmax, every contribution fits int32, the sums (< 2^31 taps) fit int64.
+    float scale[4], inv_scale[4];                                                 // 0: every finite ds of this channel is zero
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float full = int32_ok ? (float)cm * gm[i] : gm[i];
+        const bool ok = full > 0.f;
         scale[i] = uniform(ok ? __fdiv_rn(2139095040.f, full) : 0.f);            // wave-uniform: scalar registers
         inv_scale[i] = uniform(ok ? __fdiv_rn(full, 2139095040.f) : 0.f);
     }
-    // a contribution fixed point cannot carry: Inf / NaN, or anything non-zero under an overflowing bound
-    auto uncarried = [&](float dv, int i) __attribute__((always_inline)) {
-        return (__builtin_bit_cast(int, dv) & 0x7fffffff) >= 0x7f800000 || (over[i] && dv != 0.f);
-    };
+    // a contribution fixed point cannot carry: Inf / NaN
+    auto uncarried = [&](float dv) __attribute__((always_inline)) { return (__builtin_bit_cast(int, dv) & 0x7fffffff) >= 0x7f800000; };
     bool any_poison = false;
-
-    for (long long n0 = 0; n0 < N; n0 += kPlaneThreads) {
-        const long long n = n0 + tid;
-        float4 wo = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned xo = 0;
-        if (n < N) { wo = tw[n]; xo = (unsigned)tx[n]; dv = dq[n]; }
-        const float d[4] = {dv.x, dv.y, dv.z, dv.w};
-        // ---- this view's four taps into the plane (zero-weight taps -- outside the map, z <= 0 -- receive nothing: they add an
-        // integer 0 to a clamped, valid pixel).  A non-finite contribution adds 0 here and marks its pixels below.
-        const int x0 = xo & 0x7fff, x1 = x0 + ((xo >> 15) & 1), y0 = (xo >> 16) & 0x7fff, y1 = y0 + (xo >> 31);
-        const int a00 = y0 * Ws + x0, a01 = y0 * Ws + x1, a10 = y1 * Ws + x0, a11 = y1 * Ws + x1;
-        const bool taps = wo.x != 0.f || wo.y != 0.f || wo.z != 0.f || wo.w != 0.f;
-        bool nf_any = false;
-        if (taps) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool nf = uncarried(d[i], i);
-                nf_any |= nf;
-                if (scale[i] == 0.f) continue;                                    // block-uniform: nothing finite to add in this channel
-                int *pl = planes + i * cells;
-                const float dsc = nf ? 0.f : d[i] * scale[i];
-                lds_add(pl + a00, round_int(dsc * wo.x));
-                lds_add(pl + a01, round_int(dsc * wo.y));
-                lds_add(pl + a10, round_int(dsc * wo.z));
-                lds_add(pl + a11, round_int(dsc * wo.w));
-            }
-        }
-        if (__builtin_expect(__builtin_amdgcn_ballot_w64(nf_any) != 0, 0)) {     // rare: exactly the pixels a float scatter would poison
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (!taps || !uncarried(d[i], i)) continue;
-                unsigned *pm = poison + i * mask_words;
-                if (wo.x != 0.f) atomicOr(pm + (a00 >> 5), 1u << (a00 & 31));
-                if (wo.y != 0.f) atomicOr(pm + (a01 >> 5), 1u << (a01 & 31));
-                if (wo.z != 0.f) atomicOr(pm + (a10 >> 5), 1u << (a10 & 31));
-                if (wo.w != 0.f) atomicOr(pm + (a11 >> 5), 1u << (a11 & 31));
-                any_poison = true;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- the plane, once, straight into the planar gradient tensor
-    const bool poisoned = __syncthreads_or(any_poison ? 1 : 0) != 0;
     TF *const out = grad_features + (((long long)b * V + v_own) * C + 4 * q) * HW;
+
+    // one walk over the stream for channels [c_lo, c_hi); WIDE: 8-byte cells (plane index i - c_lo)
+    auto walk = [&](auto wide_tag, int c_lo, int c_hi) __attribute__((always_inline)) {
+        constexpr bool WIDE = decltype(wide_tag)::value;
+        for (long long n0 = 0; n0 < N; n0 += kPlaneThreads) {
+            const long long n = n0 + tid;
+            float4 wo = make_float4(0.f, 0.f, 0.f, 0.f), dv = make_float4(0.f, 0.f, 0.f, 0.f);
+            unsigned xo = 0;
+            if (n < N) { wo = tw[n]; xo = (unsigned)tx[n]; dv = dq[n]; }
+            const float d[4] = {dv.x, dv.y, dv.z, dv.w};
+            // ---- this view's four taps into the plane (zero-weight taps -- outside the map, z <= 0 -- receive nothing: they add an
+            // integer 0 to a clamped, valid pixel).  A non-finite contribution adds 0 here and marks its pixels below.
+            const int x0 = xo & 0x7fff, x1 = x0 + ((xo >> 15) & 1), y0 = (xo >> 16) & 0x7fff, y1 = y0 + (xo >> 31);
+            const int a00 = y0 * Ws + x0, a01 = y0 * Ws + x1, a10 = y1 * Ws + x0, a11 = y1 * Ws + x1;
+            const bool taps = wo.x != 0.f || wo.y != 0.f || wo.z != 0.f || wo.w != 0.f;
+            bool nf_any = false;
+            if (taps) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float inv = inv_scale[i];
-        const int *pl = planes + i * cells;
-        const unsigned *pm = poison + i * mask_words;
-        for (int k = tid; k < HW; k += kPlaneThreads) {
-            const int y = k / W, x = k - y * W, cell = y * Ws + x;
-            float val = (float)pl[cell] * inv;
-            if (poisoned && ((pm[cell >> 5] >> (cell & 31)) & 1u)) val = __builtin_nanf("");
-            out[(long long)i * HW + k] = from_f32<TF>(val);
+                for (int i = 0; i < 4; ++i) {
+                    if (i < c_lo || i >= c_hi) continue;
+                    const bool nf = uncarried(d[i]);
+                    nf_any |= nf;
+                    if (scale[i] == 0.f) continue;                                // block-uniform: nothing finite to add in this channel
+                    const float dsc = nf ? 0.f : d[i] * scale[i];
+                    if constexpr (WIDE) {
+                        long long *pl = reinterpret_cast<long long *>(planes) + (i - c_lo) * cells;
+                        lds_add64(pl + a00, round_int(dsc * wo.x));
+                        lds_add64(pl + a01, round_int(dsc * wo.y));
+                        lds_add64(pl + a10, round_int(dsc * wo.z));
+                        lds_add64(pl + a11, round_int(dsc * wo.w));
+                    } else {
+                        int *pl = planes + i * cells;
+                        lds_add(pl + a00, round_int(dsc * wo.x));
+                        lds_add(pl + a01, round_int(dsc * wo.y));
+                        lds_add(pl + a10, round_int(dsc * wo.z));
+                        lds_add(pl + a11, round_int(dsc * wo.w));
+                    }
+                }
+            }
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(nf_any) != 0, 0)) { // rare: exactly the pixels a float scatter would poison
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (i < c_lo || i >= c_hi || !taps || !uncarried(d[i])) continue;
+                    unsigned *pm = poison + i * mask_words;
+                    if (wo.x != 0.f) atomicOr(pm + (a00 >> 5), 1u << (a00 & 31));
+                    if (wo.y != 0.f) atomicOr(pm + (a01 >> 5), 1u << (a01 & 31));
+                    if (wo.z != 0.f) atomicOr(pm + (a10 >> 5), 1u << (a10 & 31));
+                    if (wo.w != 0.f) atomicOr(pm + (a11 >> 5), 1u << (a11 & 31));
+                    any_poison = true;
+                }
+            }
         }
+    };
+    // the plane, once, straight into the planar gradient tensor: channels [c_lo, c_hi)
+    auto write_out = [&](auto wide_tag, int c_lo, int c_hi) __attribute__((always_inline)) {
+        constexpr bool WIDE = decltype(wide_tag)::value;
+        __syncthreads();
+        const bool poisoned = __syncthreads_or(any_poison ? 1 : 0) != 0;
+        for (int i = c_lo; i < c_hi; ++i) {
+            const float inv = inv_scale[i];
+            const unsigned *pm = poison + i * mask_words;
+            for (int k = tid; k < HW; k += kPlaneThreads) {
+                const int y = k / W, x = k - y * W, cell = y * Ws + x;
+                float val;
+                if constexpr (WIDE) val = (float)((double)(reinterpret_cast<const long long *>(planes) + (i - c_lo) * cells)[cell] * (double)inv);
+                else val = (float)(planes + i * cells)[cell] * inv;
+                if (poisoned && ((pm[cell >> 5] >> (cell & 31)) & 1u)) val = __builtin_nanf("");
+                out[(long long)i * HW + k] = from_f32<TF>(val);
+            }
+        }
+    };
+    if constexpr (WIDE4) {
+        walk(std::true_type{}, 0, 4);
+        write_out(std::true_type{}, 0, 4);
+    } else if (int32_ok) {
+        walk(std::false_type{}, 0, 4);
+        write_out(std::false_type{}, 0, 4);
+    } else {
+        walk(std::true_type{}, 0, 2);
+        write_out(std::true_type{}, 0, 2);
+        __syncthreads();
+        for (int i = tid; i < plane_words; i += kPlaneThreads) planes[i] = 0;
+        __syncthreads();
+        walk(std::true_type{}, 2, 4);
+        write_out(std::true_type{}, 2, 4);
     }
 }
 
@@ -336,8 +390,9 @@ template <typename TF>
 hipError_t launch_plane_instance(const float4 *dsW, const int *dsMax, const float4 *tabW, const int *tabX, const int *cmax, TF *grad_features,
                                  const Problem &p, hipStream_t s)
 {
-    const size_t lds = plane_lds_bytes(p.H, p.W);
-    auto kern = k_bwd_plane<TF>;
+    const bool wide4 = plane_wide4(p.H, p.W);
+    const size_t lds = plane_lds_bytes(p.H, p.W, wide4 ? 8 : 4);
+    auto kern = wide4 ? k_bwd_plane<TF, true> : k_bwd_plane<TF, false>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)(p.B * p.V * (p.C / 4));
@@ -359,21 +414,19 @@ bool plane_bwd_supported(const Problem &p)
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;   // 32-bit tap offsets into the staged copy
     if ((long long)p.B * p.V * (p.C / 4) >= (1ll << 31) || p.B > 65535) return false;
     if (p.N >= (1ll << 31) / 1024 * 1024 || p.C / 4 > 65535) return false;       // grid dimensions of the Jacobian pass
-    // a FINE grid forced onto this path (variant = gather; the gate sends fine grids to the brick kernels): a plane then sums hundreds of
-    // taps per pixel and the int32 headroom for them comes out of the resolution (one bit per doubling: 8e-6 of the largest gradient
-    // observed at 220 taps per pixel, scripts/fuzz_parity.py seed 22).  Above 32 taps per pixel on average the float scatter serves.
-    if (4 * p.N > 32ll * p.H * p.W) return false;
+    // (a plane that sums hundreds of taps per pixel -- a fine grid over a coarse map, a far camera -- keeps its sums in 64 bits: the
+    // resolution does not depend on the multiplicity.  Round 3 sent those to the float scatter above 32 taps per pixel on average.)
     if (plane_table_bytes(p) > ((size_t)4 << 30)) return false;                  // a fine grid forced onto this path: keep the old scatter
     return true;
 }
 
 // [ weights float4 (B,V,N) | packed tap coordinates int (B,V,N) | max tap count int (B,V) | ds float4 (B,V,C/4,N) |
-//   max |ds| int4 (B, C/4, blocks of the Jacobian pass) ]
+//   max |ds| int4 (B, C/4, V, blocks of the Jacobian pass) ]
 size_t plane_table_bytes(const Problem &p)
 {
     const size_t bvn = (size_t)p.B * p.V * (size_t)p.N;
     return align256(bvn * sizeof(float4)) + align256(bvn * sizeof(int)) + align256((size_t)p.B * p.V * sizeof(int)) +
-           align256(bvn * (size_t)(p.C / 4) * sizeof(float4)) + align256((size_t)p.B * (p.C / 4) * ds_blocks_of(p) * 4 * sizeof(int));
+           align256(bvn * (size_t)(p.C / 4) * sizeof(float4)) + align256((size_t)p.B * (p.C / 4) * p.V * ds_blocks_of(p) * 4 * sizeof(int));
 }
 
 // featK: column-major quad-planar fp32 copy of the features; grad_features: the caller's PLANAR gradient tensor (B,V,C,Hf,Wf), every

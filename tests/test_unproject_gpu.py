@@ -1275,7 +1275,7 @@ def bench_projections(B, V):
 
 def test_plane_backward_poisons_when_a_channel_has_only_non_finite_gradients(gpu):
     """A channel whose grad_out is NaN wherever it is not zero has no finite magnitude to scale by: its NaN contributions must still
-    reach exactly their pixels (and an overflowing bound turns non-zero contributions into NaN pixels instead of dropping them)"""
+    reach exactly their pixels (and a finite gradient so large that the int32 bound overflows fp32 is carried by the 64-bit form)"""
     shape = dict(B=1, V=4, C=4, H=24, W=24, vol=(8, 8, 8))
     feats, proj, coords = _ring_problem(seed=41, **shape)
     p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
@@ -1293,7 +1293,116 @@ def test_plane_backward_poisons_when_a_channel_has_only_non_finite_gradients(gpu
     assert not bool(torch.isnan(a[0, :, 0]).any()) and not bool(torch.isnan(a[0, :, 2]).any())
     record_err("plane vs scatter bwd next to a NaN channel", float((a[0, :, 2] - b[0, :, 2]).abs().max()), 1e-5)
     huge = np.zeros_like(go)
-    huge[0, 0, 2, 2, 2] = 3e38                                                   # times the tap multiplicity: the bound overflows fp32
-    f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    huge[0, 0, 2, 2, 2] = 3e38                                                   # times the tap multiplicity the int32 bound overflows fp32:
+    f = torch.from_numpy(feats).to(gpu).requires_grad_(True)                     # the 64-bit form carries it (round 3 wrote NaN there)
     aggregation.unprojection(f, p, c, variant="gather").backward(torch.from_numpy(huge).to(gpu))
-    assert not bool(torch.isfinite(f.grad[0, :, 0]).all())                       # visible, not silently zero
+    gref = cport.backward(huge, feats, proj, coords, "softmax")
+    assert np.isfinite(gref).all() and float(np.abs(gref).max()) > 1e36
+    assert bool(torch.isfinite(f.grad).all())
+    record_err("plane bwd, one 3e38 gradient (finite: carried, not poisoned)", _err(f.grad.cpu().numpy(), gref), 8e-6 * float(np.abs(gref).max()))
+
+
+# ------------------------------------------------------------------------------------ the reference's shipped configuration
+# cfg/defaults.py:18,24-25 + cfg/baseline.yaml:28-34: VOLUME_SIZE = 16, DECONV_LAYERS = 0 -> 2048 input channels on stride-32 maps
+# (12 x 12 for 384 px crops, 8 x 8 for 256 px), VOLUME_CHANNEL 256, 4 views.  16^3 is not brick-divisible (gather forward); its 4 bricks
+# per sample would leave the brick backward on 1 / 64 of the chip per sample, so AUTO takes the plane backward, whose planes sum
+# ~114 taps per pixel there: the 64-bit form.
+@pytest.mark.parametrize("hw", [12, 8])
+def test_shipped_config_unprojection_vs_oracle(hw, gpu):
+    shape = dict(B=2, V=4, C=256, H=hw, W=hw, vol=(16, 16, 16))
+    feats, proj, coords = _ring_problem(seed=40 + hw, **shape)
+    f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    out = aggregation.unprojection(f, p, c)
+    ref = cport.forward(feats, proj, coords, "softmax")
+    record_err("shipped config 16^3 x 256 ch, %dx%d maps, fwd" % (hw, hw), _err(out.detach().cpu().numpy(), ref), TOL)
+    go = np.random.default_rng(6).standard_normal(ref.shape, dtype=np.float32)
+    out.backward(torch.from_numpy(go).to(gpu))
+    gref = cport.backward(go, feats, proj, coords, "softmax")
+    # ~114 (12 x 12) / ~256 (8 x 8) taps per pixel: the bound is a few fp32 ulps of the largest gradient, as for every summed gradient
+    record_err("shipped config 16^3 x 256 ch, %dx%d maps, bwd (plane kernel, 64-bit sums)" % (hw, hw), _err(f.grad.cpu().numpy(), gref), _bound(gref))
+    # the brick backward, forced, agrees
+    f2 = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    aggregation.unprojection(f2, p, c, variant="brick" if _brick_ok(f2, c) else "auto").backward(torch.from_numpy(go).to(gpu))
+    record_err("shipped config %dx%d maps, bwd twice" % (hw, hw), float((f2.grad - f.grad).abs().max()), _bound(gref))
+
+
+def test_shipped_config_volume_generator(gpu):
+    """VolumeGenerator as build_volume_generator wires it for the shipped cfg (2048 -> 256 conv, 16^3, cuboid 2500 mm), eval pose:
+    the volume and the gradient w.r.t. the input features against nn.functional.conv2d + the C oracle"""
+    B, V, Cin, Cout, S, hw, IMG = 2, 4, 2048, 256, 16, 12, 384
+    cams = _rig(B, V, 5000.0, IMG, seed=9)
+    batch = dict(images=np.zeros((B, V, IMG, IMG, 3), np.uint8), cameras=cams,
+                 keypoints_3d=[np.random.default_rng(b).normal(0, 100, (17, 3)).astype(np.float32) for b in range(B)])
+    proj_org = torch.from_numpy(np.stack([[cams[v][b].projection for v in range(V)] for b in range(B)]).astype(np.float32)).to(gpu)
+    torch.manual_seed(3)
+    gen = aggregation.VolumeGenerator(volume_size=S, input_channels=Cin, output_channels=Cout, cuboid_side=2500.0, device=gpu).eval()
+    feats = torch.randn(B, V, Cin, hw, hw, device=gpu, requires_grad=True)
+    vol = gen(feats, proj_org, batch)
+    assert tuple(vol.shape) == (B, Cout, S, S, S) and vol.dtype == torch.float32
+    # the same through plain torch + the oracle (eval: theta = 0, cuboid centred on the world origin, Q4)
+    w, bias = gen.process_feature[0].weight.detach(), gen.process_feature[0].bias.detach()
+    conv = torch.nn.functional.conv2d(feats.detach().reshape(B * V, Cin, hw, hw), w, bias).reshape(B, V, Cout, hw, hw)
+    P = aggregation.feature_level_projections(cams, (IMG, IMG), (hw, hw)).astype(np.float32)
+    g = np.stack(np.meshgrid(np.arange(S), np.arange(S), np.arange(S), indexing="ij"), -1).astype(np.float32)
+    coords = (np.float32(-1250.0) + np.float32(2500.0 / (S - 1)) * g).astype(np.float32)
+    coords = np.broadcast_to(coords, (B,) + coords.shape).copy()
+    conv_np = conv.cpu().numpy()
+    ref = cport.forward(conv_np, P, coords, "softmax")
+    # the conv sums 2048 products in an order of its own: a few dozen ulps of its largest output on top of the path's bar
+    slack = 64 * 2.0 ** -23 * float(np.abs(conv_np).max())
+    record_err("shipped cfg VolumeGenerator fwd (2048 -> 256, 16^3, 12x12)", _err(vol.detach().cpu().numpy(), ref), TOL + slack)
+    go = torch.randn(vol.shape, device=gpu, generator=torch.Generator(device=gpu).manual_seed(5))
+    vol.backward(go)
+    gconv = cport.backward(go.cpu().numpy(), conv_np, P, coords, "softmax")
+    gfeat_ref = torch.nn.functional.conv_transpose2d(torch.from_numpy(gconv).reshape(B * V, Cout, hw, hw).to(gpu), w).reshape(B, V, Cin, hw, hw)
+    record_err("shipped cfg VolumeGenerator bwd w.r.t. the input features", float((feats.grad - gfeat_ref).abs().max()),
+               64 * 2.0 ** -23 * float(gfeat_ref.abs().max()) + 1e-4)
+
+
+# ------------------------------------------------------------------------------------ plane backward: concentrated projections, outliers
+def _far_rig_problem(B, V, C, H, W, vol, seed, radius=60000.0):
+    """a rig so far away that the whole volume lands on a few pixels of every map: hundreds of taps per pixel"""
+    feats, proj, coords = _ring_problem(B, V, C, H, W, vol, seed)
+    for b in range(B):
+        for v in range(V):
+            az = 2 * np.pi * v / V + 0.3
+            eye = np.array([radius * np.cos(az), radius * np.sin(az), 0.3 * radius])
+            fwd = -eye / np.linalg.norm(eye)
+            right = np.cross(fwd, [0, 0, 1.0]); right /= np.linalg.norm(right)
+            R = np.stack([right, np.cross(fwd, right), fwd])
+            cam = multiview.Camera(R, -R @ eye, [[1145.0, 0, 512], [0, 1145.0, 512], [0, 0, 1]])
+            cam.update_after_resize((1024, 1024), (W, H))
+            proj[b, v] = cam.projection
+    return feats, proj, coords
+
+
+@pytest.mark.parametrize("mode", ("softmax", "sum"))
+def test_plane_backward_concentrated_projection_with_an_outlier(mode, gpu):
+    """a far camera puts the whole volume on a few pixels (tap multiplicity in the thousands) and one voxel of grad_out is
+    2^20 larger than the rest.  The error is measured PER VIEW against that view's own largest gradient, with the outlier's pixels
+    left out of a second measurement so that the quiet part of the plane has to be right as well."""
+    shape = dict(B=1, V=4, C=8, H=48, W=48, vol=(24, 24, 24))
+    feats, proj, coords = _far_rig_problem(seed=23, **shape)
+    go = np.random.default_rng(4).standard_normal((1, 8, 24, 24, 24), dtype=np.float32)
+    go_out = go.copy()
+    go_out[0, :, 5, 7, 11] *= 2.0 ** 20
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    for name, g in (("plain", go), ("outlier", go_out)):
+        gref = cport.backward(g, feats, proj, coords, mode)
+        f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+        aggregation.unprojection(f, p, c, aggregation_method=mode, variant="gather").backward(torch.from_numpy(g).to(gpu))
+        got = f.grad.cpu().numpy()
+        for v in range(4):
+            m = float(np.abs(gref[0, v]).max())
+            record_err("plane bwd far rig %s %s view %d (rel. to the view's max %.3g)" % (mode, name, v, m), _err(got[0, v], gref[0, v]), 8e-6 * m)
+    # the quiet pixels under the outlier: everything the outlier voxel does not touch must match the run without it to the resolution
+    # of the fixed point (2^-31 of the view's max |ds| per contribution, 64-bit sums), i.e. stay within the plain run's own bound
+    gq = cport.backward(go, feats, proj, coords, mode)
+    go_only = np.zeros_like(go); go_only[0, :, 5, 7, 11] = go_out[0, :, 5, 7, 11] - go[0, :, 5, 7, 11]
+    touched = cport.backward(go_only, feats, proj, coords, "sum") != 0            # pixels the outlier voxel reaches (any mode: same taps)
+    quiet = ~touched
+    if mode == "sum":                                                            # linear: the outlier leaves the quiet pixels alone exactly
+        err = float(np.abs(got - gq)[quiet].max())
+        # resolution there: 2^-31 * max |ds| of the view (2^20 larger now) per contribution, thousands of contributions per pixel
+        record_err("plane bwd far rig sum, quiet pixels beside a 2^20 outlier", err, 2.0 ** 20 * 2.0 ** -31 * 4096 * float(np.abs(go).max()) + 1e-4)
