@@ -48,10 +48,10 @@ struct PlaneShared {
 };
 
 __host__ __device__ inline int plane_row_stride(int W) { return W | 1; }
-__host__ __device__ inline size_t plane_lds_bytes(int H, int W, int cell_bytes = 4)
+__host__ __device__ inline size_t plane_lds_bytes(int H, int W, int cell_bytes = 4, int copies = 1)
 {
     const size_t cells = (size_t)H * plane_row_stride(W);
-    return 4 * cells * cell_bytes + 4 * ((cells + 31) / 32) * sizeof(int) + sizeof(PlaneShared);
+    return 4 * cells * cell_bytes * copies + 4 * ((cells + 31) / 32) * sizeof(int) + sizeof(PlaneShared);
 }
 // maps small enough for 8-byte cells of all four channels
 __host__ __device__ inline bool plane_wide4(int H, int W) { return plane_lds_bytes(H, W, 8) <= (size_t)kPlaneLdsBytes; }
@@ -206,24 +206,31 @@ __device__ __forceinline__ void lds_add64(long long *p, int v)
     __hip_atomic_fetch_add(p, (long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-template <typename TF, bool WIDE4>
-__global__ void __launch_bounds__(1024)
+// COPIES (8-byte cells only): the block keeps that many private images of the four planes, one per 16-lane group of a wave.  Small
+// maps are where many voxels share a pixel (the reference's shipped 16^3 volume over 12 x 12 maps: ~114 taps per pixel): the four
+// columns a wave walks at a time land on the same few pixels, and same-address LDS atomics of one instruction are served one after
+// the other.  With a copy per 16-lane group only the z-neighbours of one column still meet.
+// NT: 1024 threads for planes that fill the LDS (one block per CU); 256 for small maps, whose blocks are short (a 16^3 volume is four
+// iterations of 1024 threads): eight resident blocks per CU hide each other's load latency.
+template <typename TF, bool WIDE4, int COPIES, int NT>
+__global__ void __launch_bounds__(NT)
 k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int ds_blocks, const float4 *__restrict__ tabW,
             const int *__restrict__ tabX, const int *__restrict__ cmax, TF *__restrict__ grad_features, int C, int V, int H, int W, long long N,
             Gate gate)
 {
     if (gated_off(gate)) return;
-    constexpr int kPlaneThreads = 1024;
+    constexpr int kPlaneThreads = NT;
     extern __shared__ __align__(16) unsigned char smem[];
     const int Ws = plane_row_stride(W), cells = H * Ws, mask_words = (cells + 31) >> 5;
     constexpr int CELL = WIDE4 ? 8 : 4;                                          // bytes per cell of the four-channel image
     int *const planes = reinterpret_cast<int *>(smem);                           // [4][cells] int32, [2][cells] / [4][cells] int64
-    unsigned *const poison = reinterpret_cast<unsigned *>(smem + (size_t)4 * cells * CELL);   // [4][mask_words]
+    unsigned *const poison = reinterpret_cast<unsigned *>(smem + (size_t)4 * cells * CELL * COPIES);   // [4][mask_words]
     PlaneShared *const sh = reinterpret_cast<PlaneShared *>(poison + 4 * mask_words);
     const int tid = threadIdx.x;
     const int nq = C >> 2, HW = H * W;
     const int q = blockIdx.x % nq, v_own = (blockIdx.x / nq) % V, b = blockIdx.x / (nq * V);
-    const int plane_words = 4 * cells * (CELL / 4);
+    const int plane_words = 4 * cells * (CELL / 4) * COPIES;
+    const int copy_off = COPIES > 1 ? ((tid >> 4) & (COPIES - 1)) * 4 * cells : 0;     // this lane group's image (8-byte cells)
 
     for (int i = tid; i < plane_words + 4 * mask_words; i += kPlaneThreads) planes[i] = 0;    // the bit planes follow the planes
     if (tid < 4) sh->gmax[tid] = 0;
@@ -288,7 +295,7 @@ k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int d
                     if (scale[i] == 0.f) continue;                                // block-uniform: nothing finite to add in this channel
                     const float dsc = nf ? 0.f : d[i] * scale[i];
                     if constexpr (WIDE) {
-                        long long *pl = reinterpret_cast<long long *>(planes) + (i - c_lo) * cells;
+                        long long *pl = reinterpret_cast<long long *>(planes) + copy_off + (i - c_lo) * cells;
                         lds_add64(pl + a00, round_int(dsc * wo.x));
                         lds_add64(pl + a01, round_int(dsc * wo.y));
                         lds_add64(pl + a10, round_int(dsc * wo.z));
@@ -327,7 +334,13 @@ k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int d
             for (int k = tid; k < HW; k += kPlaneThreads) {
                 const int y = k / W, x = k - y * W, cell = y * Ws + x;
                 float val;
-                if constexpr (WIDE) val = (float)((double)(reinterpret_cast<const long long *>(planes) + (i - c_lo) * cells)[cell] * (double)inv);
+                if constexpr (WIDE) {
+                    const long long *pl = reinterpret_cast<const long long *>(planes) + (i - c_lo) * cells;
+                    long long acc = pl[cell];
+#pragma unroll
+                    for (int k2 = 1; k2 < COPIES; ++k2) acc += pl[k2 * 4 * cells + cell];
+                    val = (float)((double)acc * (double)inv);
+                }
                 else val = (float)(planes + i * cells)[cell] * inv;
                 if (poisoned && ((pm[cell >> 5] >> (cell & 31)) & 1u)) val = __builtin_nanf("");
                 out[(long long)i * HW + k] = from_f32<TF>(val);
@@ -391,12 +404,13 @@ hipError_t launch_plane_instance(const float4 *dsW, const int *dsMax, const floa
                                  const Problem &p, hipStream_t s)
 {
     const bool wide4 = plane_wide4(p.H, p.W);
-    const size_t lds = plane_lds_bytes(p.H, p.W, wide4 ? 8 : 4);
-    auto kern = wide4 ? k_bwd_plane<TF, true> : k_bwd_plane<TF, false>;
+    const bool copies4 = wide4 && plane_lds_bytes(p.H, p.W, 8, 4) <= (size_t)kPlaneLdsBytes / 8;   // eight blocks per CU (maps up to ~16 x 16)
+    const size_t lds = plane_lds_bytes(p.H, p.W, wide4 ? 8 : 4, copies4 ? 4 : 1);
+    auto kern = copies4 ? k_bwd_plane<TF, true, 4, 256> : wide4 ? k_bwd_plane<TF, true, 1, 1024> : k_bwd_plane<TF, false, 1, 1024>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const unsigned grid = (unsigned)(p.B * p.V * (p.C / 4));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, dsW, dsMax, ds_blocks_of(p), tabW, tabX, cmax, grad_features, p.C, p.V, p.H, p.W, p.N,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(copies4 ? 256 : 1024), lds, s, dsW, dsMax, ds_blocks_of(p), tabW, tabX, cmax, grad_features, p.C, p.V, p.H, p.W, p.N,
                        make_gate(p, false));
     return hipGetLastError();
 }
