@@ -6,71 +6,80 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from multiviewhmr_amd import aggregation, multiview
 from oracle import cport
-ap = argparse.ArgumentParser(); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--cases", type=int, default=60)
-ap.add_argument("--big", action="store_true", help="maps of 60..220 px, volumes up to 16 x 16 x 64: windows near / beyond the LDS pool")
-ap.add_argument("--dtype", default="f32", choices=("f32", "f16", "bf16"), help="f16: fp16 features and volume; bf16: fp32 features, bf16 volume / grad_out")
-a = ap.parse_args()
-gpu = torch.device("cuda:0")
-MODES = ("softmax", "sum", "mean", "max")
-def bound(ref):
-    m = float(np.abs(ref).max()); return 1e-4 if m <= 16.0 else max(1e-4, 8e-6 * m)
-def err(x, r): return float(np.abs(np.asarray(x, dtype=np.float64) - r).max())
-rng = np.random.default_rng(a.seed)
-worst = 0.0; n = 0
-for case in range(a.cases):
-    V = int(rng.choice([2, 4, 4, 8])); C = int(rng.choice([4, 8, 12, 20]))
-    H, W = int(rng.integers(12, 60)), int(rng.integers(12, 60))
-    X, Y, Z = int(rng.choice([4, 8, 12, 16])), int(rng.choice([8, 16])), int(rng.choice([16, 32, 64]))
-    if a.big:
-        H, W = int(rng.integers(60, 220)), int(rng.integers(60, 220))
-        X, Y, Z = int(rng.choice([8, 16])), int(rng.choice([8, 12, 16])), int(rng.choice([32, 64]))
-        C = int(rng.choice([4, 8]))
-    B = int(rng.integers(1, 3))
-    side = float(rng.uniform(600.0, 3000.0)); centre = rng.uniform(-300.0, 300.0, 3)
-    theta = float(rng.uniform(0, 2 * np.pi)); radius = float(rng.uniform(1200.0, 6000.0)); focal = float(rng.uniform(700.0, 1800.0))
-    feats = rng.standard_normal((B, V, C, H, W), dtype=np.float32) * float(rng.choice([0.3, 1.0, 4.0, 12.0]))
-    proj = np.empty((B, V, 3, 4), np.float32)
-    up = [0, 0, 1.0] if rng.random() < 0.7 else [0, 1.0, 0.2]                    # some rigs rolled: volume z no longer along image y
-    for b in range(B):
-        for v in range(V):
-            az = 2 * np.pi * v / V + rng.uniform(-0.2, 0.2)
-            eye = np.array([radius * np.cos(az), radius * np.sin(az), rng.uniform(500.0, 2500.0)])
-            fwd = (centre - eye) / np.linalg.norm(centre - eye)
-            right = np.cross(fwd, up); right /= np.linalg.norm(right)
-            R = np.stack([right, np.cross(fwd, right), fwd])
-            cam = multiview.Camera(R, -R @ eye, [[focal, 0, 512], [0, focal, 512], [0, 0, 1]])
-            cam.update_after_resize((1024, 1024), (W, H))
-            proj[b, v] = cam.projection
-    g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij"), -1).astype(np.float64)
-    pts = -side / 2 + g * (side / (np.array([X, Y, Z]) - 1))
-    ct, st = np.cos(theta), np.sin(theta)
-    pts = pts @ np.array([[ct, -st, 0], [st, ct, 0], [0, 0, 1.0]]).T + centre
-    coords = np.broadcast_to(pts.astype(np.float32), (B,) + pts.shape).copy()
-    mode = MODES[case % 4]
-    tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
-    if a.dtype == "f16": feats = torch.from_numpy(feats).half().float().numpy()   # the oracle sees the rounded inputs
-    ref = cport.forward(feats, proj, coords, mode)
-    go = torch.from_numpy(rng.standard_normal(ref.shape, dtype=np.float32)).to(tdt).float().numpy()
-    gref = cport.backward(go, feats, proj, coords, mode)
-    # half-precision storage: half an ulp of the stored magnitude on top of the fp32 bar (as tests/test_unproject_gpu.py)
-    ulp = {"f32": 0.0, "f16": 2.0 ** -11, "bf16": 2.0 ** -8}[a.dtype]
-    gulp = {"f32": 0.0, "f16": 2.0 ** -10, "bf16": 0.0}[a.dtype]                 # bf16 volume: the feature gradient stays fp32
-    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
-    for variant in ("auto", "brick", "gather"):
-        f = torch.from_numpy(feats).to(gpu)
-        if a.dtype == "f16": f = f.half()
-        f = f.requires_grad_(True)
-        try:
-            out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant=variant, **({"out_dtype": torch.bfloat16} if a.dtype == "bf16" else {}))
-        except (ValueError, RuntimeError) as e:
-            if variant == "brick": continue                                       # shape the brick kernels do not take
-            raise
-        assert out.dtype == tdt
-        out.backward(torch.from_numpy(go).to(gpu).to(tdt))
-        e1 = err(out.detach().float().cpu().numpy(), ref) / (bound(ref) + ulp * float(np.abs(ref).max()))
-        e2 = err(f.grad.float().cpu().numpy(), gref) / (bound(gref) + gulp * float(np.abs(gref).max()))
-        n += 1
-        if max(e1, e2) > worst:
-            worst = max(e1, e2); print("case %d %s V%d C%d %dx%d vol%s %s: fwd %.3g bwd %.3g of the bound" % (case, variant, V, C, H, W, (X, Y, Z), mode, e1, e2), flush=True)
-        assert e1 <= 1.0 and e2 <= 1.0, (case, variant, V, C, H, W, (X, Y, Z), mode, e1, e2)
-print("seed %d: %d runs, worst error / bound = %.3g" % (a.seed, n, worst))
+def run(seed=1, cases=60, big=False, dtype="f32", verbose=True):
+    """-> (runs, worst error / bound); asserts every error within its bound"""
+    import types
+    a = types.SimpleNamespace(seed=seed, cases=cases, big=big, dtype=dtype)
+    gpu = torch.device("cuda:0")
+    MODES = ("softmax", "sum", "mean", "max")
+    def bound(ref):
+        m = float(np.abs(ref).max()); return 1e-4 if m <= 16.0 else max(1e-4, 8e-6 * m)
+    def err(x, r): return float(np.abs(np.asarray(x, dtype=np.float64) - r).max())
+    rng = np.random.default_rng(a.seed)
+    worst = 0.0; n = 0
+    for case in range(a.cases):
+        V = int(rng.choice([2, 4, 4, 8])); C = int(rng.choice([4, 8, 12, 20]))
+        H, W = int(rng.integers(12, 60)), int(rng.integers(12, 60))
+        X, Y, Z = int(rng.choice([4, 8, 12, 16])), int(rng.choice([8, 16])), int(rng.choice([16, 32, 64]))
+        if a.big:
+            H, W = int(rng.integers(60, 220)), int(rng.integers(60, 220))
+            X, Y, Z = int(rng.choice([8, 16])), int(rng.choice([8, 12, 16])), int(rng.choice([32, 64]))
+            C = int(rng.choice([4, 8]))
+        B = int(rng.integers(1, 3))
+        side = float(rng.uniform(600.0, 3000.0)); centre = rng.uniform(-300.0, 300.0, 3)
+        theta = float(rng.uniform(0, 2 * np.pi)); radius = float(rng.uniform(1200.0, 6000.0)); focal = float(rng.uniform(700.0, 1800.0))
+        feats = rng.standard_normal((B, V, C, H, W), dtype=np.float32) * float(rng.choice([0.3, 1.0, 4.0, 12.0]))
+        proj = np.empty((B, V, 3, 4), np.float32)
+        up = [0, 0, 1.0] if rng.random() < 0.7 else [0, 1.0, 0.2]                    # some rigs rolled: volume z no longer along image y
+        for b in range(B):
+            for v in range(V):
+                az = 2 * np.pi * v / V + rng.uniform(-0.2, 0.2)
+                eye = np.array([radius * np.cos(az), radius * np.sin(az), rng.uniform(500.0, 2500.0)])
+                fwd = (centre - eye) / np.linalg.norm(centre - eye)
+                right = np.cross(fwd, up); right /= np.linalg.norm(right)
+                R = np.stack([right, np.cross(fwd, right), fwd])
+                cam = multiview.Camera(R, -R @ eye, [[focal, 0, 512], [0, focal, 512], [0, 0, 1]])
+                cam.update_after_resize((1024, 1024), (W, H))
+                proj[b, v] = cam.projection
+        g = np.stack(np.meshgrid(np.arange(X), np.arange(Y), np.arange(Z), indexing="ij"), -1).astype(np.float64)
+        pts = -side / 2 + g * (side / (np.array([X, Y, Z]) - 1))
+        ct, st = np.cos(theta), np.sin(theta)
+        pts = pts @ np.array([[ct, -st, 0], [st, ct, 0], [0, 0, 1.0]]).T + centre
+        coords = np.broadcast_to(pts.astype(np.float32), (B,) + pts.shape).copy()
+        mode = MODES[case % 4]
+        tdt = {"f32": torch.float32, "f16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
+        if a.dtype == "f16": feats = torch.from_numpy(feats).half().float().numpy()   # the oracle sees the rounded inputs
+        ref = cport.forward(feats, proj, coords, mode)
+        go = torch.from_numpy(rng.standard_normal(ref.shape, dtype=np.float32)).to(tdt).float().numpy()
+        gref = cport.backward(go, feats, proj, coords, mode)
+        # half-precision storage: half an ulp of the stored magnitude on top of the fp32 bar (as tests/test_unproject_gpu.py)
+        ulp = {"f32": 0.0, "f16": 2.0 ** -11, "bf16": 2.0 ** -8}[a.dtype]
+        gulp = {"f32": 0.0, "f16": 2.0 ** -10, "bf16": 0.0}[a.dtype]                 # bf16 volume: the feature gradient stays fp32
+        p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+        for variant in ("auto", "brick", "gather"):
+            f = torch.from_numpy(feats).to(gpu)
+            if a.dtype == "f16": f = f.half()
+            f = f.requires_grad_(True)
+            try:
+                out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant=variant, **({"out_dtype": torch.bfloat16} if a.dtype == "bf16" else {}))
+            except (ValueError, RuntimeError) as e:
+                if variant == "brick": continue                                       # shape the brick kernels do not take
+                raise
+            assert out.dtype == tdt
+            out.backward(torch.from_numpy(go).to(gpu).to(tdt))
+            e1 = err(out.detach().float().cpu().numpy(), ref) / (bound(ref) + ulp * float(np.abs(ref).max()))
+            e2 = err(f.grad.float().cpu().numpy(), gref) / (bound(gref) + gulp * float(np.abs(gref).max()))
+            n += 1
+            if max(e1, e2) > worst:
+                worst = max(e1, e2); verbose and print("case %d %s V%d C%d %dx%d vol%s %s: fwd %.3g bwd %.3g of the bound" % (case, variant, V, C, H, W, (X, Y, Z), mode, e1, e2), flush=True)
+            assert e1 <= 1.0 and e2 <= 1.0, (case, variant, V, C, H, W, (X, Y, Z), mode, e1, e2)
+    return n, worst
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser(); ap.add_argument("--seed", type=int, default=1); ap.add_argument("--cases", type=int, default=60)
+    ap.add_argument("--big", action="store_true", help="maps of 60..220 px, volumes up to 16 x 16 x 64: windows near / beyond the LDS pool")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "f16", "bf16"), help="f16: fp16 features and volume; bf16: fp32 features, bf16 volume / grad_out")
+    a = ap.parse_args()
+    n, worst = run(a.seed, a.cases, a.big, a.dtype)
+    print("seed %d: %d runs, worst error / bound = %.3g" % (a.seed, n, worst))

@@ -1406,3 +1406,123 @@ def test_plane_backward_concentrated_projection_with_an_outlier(mode, gpu):
         err = float(np.abs(got - gq)[quiet].max())
         # resolution there: 2^-31 * max |ds| of the view (2^20 larger now) per contribution, thousands of contributions per pixel
         record_err("plane bwd far rig sum, quiet pixels beside a 2^20 outlier", err, 2.0 ** 20 * 2.0 ** -31 * 4096 * float(np.abs(go).max()) + 1e-4)
+
+
+# ------------------------------------------------------------------------------------ full-tensor parity at the headline size
+def _max_diff_chunked(a, b, chunk=4):
+    """max |a - b| over two (B, C, X, Y, Z) device tensors without a full-size temporary"""
+    worst = 0.0
+    for i in range(0, a.shape[0], chunk):
+        worst = max(worst, float((a[i:i + chunk].float() - b[i:i + chunk].float()).abs().max()))
+    return worst
+
+
+def test_northstar_full_tensor_brick_vs_gather_with_the_bench_rigs(gpu):
+    """the headline workload exactly as bench.py builds it (per-sample camera radii, bench.ring_projections), every one
+    of the 32 x 256 channel planes: the brick kernels (LDS windows, parity split, z-run lane map) against the gather kernels (one wave
+    per voxel, channels-last rows) -- two decompositions that share only make_taps.  The oracle pins a slice."""
+    import bench
+    B, V, C, H, S = 32, 4, 256, 96, 64
+    torch.manual_seed(0)
+    f = torch.randn(B, V, C, H, H, device=gpu)
+    P = bench.ring_projections(B, V, (H, H), seed=0)
+    coords_np = bench.cuboid_volume(1, S)
+    p = torch.from_numpy(P).to(gpu)
+    c = torch.from_numpy(coords_np).to(gpu).expand(B, S, S, S, 3).contiguous()
+    out_b = aggregation.unprojection(f, p, c, variant="brick")
+    out_g = aggregation.unprojection(f, p, c, variant="gather")
+    # same taps, same weights; the bilinear sum runs in another order for odd rows (brick_fwd_kernel.h) and the softmax relative to
+    # view 0 instead of the maximum: a few ulps of values of magnitude ~5
+    record_err("north star, all 32 x 256 planes: brick vs gather fwd", _max_diff_chunked(out_b, out_g), 1e-5)
+    for b in (0, 17, 31):                                                          # different radii per sample
+        err, ref = _oracle_on_channels(f, p, c, out_b, [3, 200], b=b)
+        record_err("north star bench rig, sample %d, 2 channels vs oracle" % b, err, TOL)
+    del out_g
+    # backward: grad_out = the forward output; brick (LDS fixed point + float atomics) vs gather (per-tap float atomics)
+    go = out_b
+    gb = aggregation._op_backward(go, f, p, c, 0, _capi.F32, _capi.VARIANT["brick"])
+    gg = aggregation._op_backward(go, f, p, c, 0, _capi.F32, _capi.VARIANT["gather"])
+    m = float(gg.abs().max())
+    record_err("north star, all 32 x 4 x 256 gradient planes: brick vs gather bwd (largest %.3g)" % m, _max_diff_chunked(gb, gg), 8e-6 * m + 1e-5)
+
+
+def test_northstar_full_tensor_cuboid_route_rotated(gpu):
+    """The cuboid route (voxel centres evaluated in the kernels) at the headline size with theta != 0 and per-sample pivots, as
+    VolumeGenerator drives it in training: brick vs gather over the whole tensor, and against the tensor route on coordinates
+    materialised by mvhmr_build_coord_volumes (bit-equal centres: the two routes must agree exactly, kernel by kernel)"""
+    import bench
+    from multiviewhmr_amd import volumetric
+    B, V, C, H, S = 32, 4, 256, 96, 64
+    torch.manual_seed(1)
+    rng = np.random.default_rng(11)
+    f = torch.randn(B, V, C, H, H, device=gpu)
+    p = torch.from_numpy(bench.ring_projections(B, V, (H, H), seed=3)).to(gpu)
+    thetas = rng.uniform(0.0, 2 * np.pi, B)
+    rots = torch.from_numpy(np.stack([volumetric.get_rotation_matrix([0, 0, 1], t) for t in thetas]).astype(np.float32)).to(gpu)
+    centers = torch.from_numpy(rng.normal(0, 100, (B, 3)).astype(np.float32)).to(gpu)
+    position, sides = (-1250.0, -1250.0, -1250.0), (2500.0, 2500.0, 2500.0)
+    kw = dict(position=position, sides=sides, volume_shape=(S, S, S))
+    out_b = aggregation.unprojection_cuboid(f, p, rots, centers, variant="brick", **kw)
+    out_g = aggregation.unprojection_cuboid(f, p, rots, centers, variant="gather", **kw)
+    record_err("north star cuboid route, theta != 0, all planes: brick vs gather fwd", _max_diff_chunked(out_b, out_g), 1e-5)
+    del out_g
+    gen = aggregation.VolumeGenerator(volume_size=S, input_channels=4, output_channels=4, cuboid_side=2500.0, device=gpu)
+    assert tuple(gen.cuboid().position) == position and tuple(gen.cuboid().sides) == sides
+    coords = gen.coord_volumes(rots, centers, gpu)                                 # mvhmr_build_coord_volumes
+    out_t = aggregation.unprojection(f, p, coords, variant="brick")
+    assert torch.equal(out_t, out_b)                                               # same centres, same kernel: bit-equal
+    err, ref = _oracle_on_channels(f, p, coords, out_b, [0, 131], b=9)
+    record_err("north star cuboid route, sample 9, 2 channels vs oracle", err, TOL)
+
+
+@pytest.mark.parametrize("seed,big", [(1, False), (22, False), (5, True)])
+def test_fuzz_parity_fixed_seeds(seed, big, gpu):
+    """three fixed seeds of scripts/fuzz_parity.py (random rigs incl. rolled ones, cuboids, volumes, maps, every variant, forward +
+    backward against the C oracle); seed 22 is the one that found the fine-grid plane route in round 3"""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    n, worst = fz.run(seed=seed, cases=16 if big else 24, big=big, verbose=False)
+    record_err("fuzz seed %d%s: %d runs, worst error / bound" % (seed, " --big" if big else "", n), worst, 1.0)
+
+
+# ------------------------------------------------------------------------------------ (f)3: the consumer's first stage on a bf16 volume
+def test_bf16_volume_through_the_regressors_first_stage(gpu):
+    """VolumeGenerator(volume_dtype=bfloat16) feeding the encoder's first stage -- Conv3d(256 -> 128, 3) + BatchNorm3d
+    + ReLU (models/regressor.py:26-32,78-80) -- under autocast, and back: the gradient w.r.t. the input features against the fp32
+    route with the bf16 bound (the volume and its gradient are rounded to 8 bits once each)."""
+    B, V, C, H, S, IMG = 2, 4, 256, 32, 32, 128
+    cams = _rig(B, V, 5000.0, IMG, seed=4)
+    batch = dict(images=np.zeros((B, V, IMG, IMG, 3), np.uint8), cameras=cams,
+                 keypoints_3d=[np.random.default_rng(b).normal(0, 100, (17, 3)).astype(np.float32) for b in range(B)])
+    proj_org = torch.from_numpy(np.stack([[cams[v][b].projection for v in range(V)] for b in range(B)]).astype(np.float32)).to(gpu)
+    torch.manual_seed(8)
+    stage = torch.nn.Sequential(torch.nn.Conv3d(C, 128, 3, padding=1), torch.nn.BatchNorm3d(128), torch.nn.ReLU(True)).to(gpu).train()
+    x = torch.randn(B, V, C, H, H, device=gpu)
+    go = torch.randn(B, 128, S, S, S, device=gpu) / (B * 128 * S ** 3) ** 0.5
+    grads, vols = {}, {}
+    # three routes: fp32 volume + fp32 stage | bf16 volume from the kernels + autocast stage | fp32 volume rounded by torch + autocast stage
+    for route in ("fp32", "bf16", "fp32->bf16"):
+        torch.manual_seed(9)
+        dt = torch.bfloat16 if route == "bf16" else torch.float32
+        gen = aggregation.VolumeGenerator(volume_size=S, input_channels=C, output_channels=C, device=gpu, volume_dtype=dt).eval()
+        xi = x.clone().requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=route != "fp32"):
+            vol = gen(xi, proj_org, batch)
+            assert vol.dtype == dt
+            y = stage(vol.to(torch.bfloat16) if route == "fp32->bf16" else vol)
+        y.float().backward(go)
+        grads[route], vols[route] = xi.grad.clone(), vol.detach().float()
+        stage.zero_grad(set_to_none=True)
+    vm = float(vols["fp32"].abs().max())
+    record_err("bf16 volume vs fp32 volume (consumer test)", float((vols["bf16"] - vols["fp32"]).abs().max()), vm * 2.0 ** -8 + 1e-4)
+    assert torch.equal(vols["bf16"], vols["fp32"].to(torch.bfloat16).float())      # the kernels' bf16 volume IS the fp32 volume rounded once
+    # so the consumer sees identical inputs on the last two routes and hands back identical bf16 gradients: the feature gradients may
+    # differ only by the order of the float atomics
+    gm = float(grads["fp32->bf16"].abs().max())
+    record_err("bf16 volume route vs fp32 volume rounded by torch: gradient w.r.t. the features (largest %.3g)" % gm,
+               float((grads["bf16"] - grads["fp32->bf16"]).abs().max()), 8e-6 * gm + 1e-7)
+    # against the all-fp32 route the difference is the consumer's own bf16 arithmetic (conv inputs, BatchNorm statistics, ReLU masks)
+    rel = float((grads["bf16"] - grads["fp32"]).norm() / grads["fp32"].norm())
+    record_err("bf16 consumer route vs the all-fp32 route: relative L2 error of the feature gradient", rel, 0.1)
