@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define MVHMR_ABI_VERSION 2   /* 2: MVHMR_LAYOUT_QUAD became column-major (B,V,C/4,Wf,Hf,4) */
+#define MVHMR_ABI_VERSION 3   /* 2: MVHMR_LAYOUT_QUAD became column-major (B,V,C/4,Wf,Hf,4).  3: QUAD + AUTO is geometry-gated and needs its
+                                 workspace; explicit GATHER with QUAD input is served; MVHMR_BF16 out_dtype; mvhmr_unproject_backward_supported,
+                                 mvhmr_triangulate_dlt (ABI history) */
 
 typedef enum mvhmr_status_t {
     MVHMR_OK = 0,
@@ -84,7 +86,14 @@ typedef enum mvhmr_variant_t {
                                  when vol_y % 8 == 0; the forward doubles the bricks in x when vol_x % 8 == 0 for 2 / 4 views; the
                                  backward uses 8 x 8 x 16 -- 8 x 4 x 16 with 8 views -- when the volume divides that way);
                                  the backward needs one storage type throughout;
-                                 anything else is MVHMR_ERR_UNSUPPORTED */
+                                 anything else is MVHMR_ERR_UNSUPPORTED.
+                                 What therefore runs the GATHER family under AUTO: view counts other than 2 / 4 / 8; vol_z % 32 != 0 in
+                                 the forward (the reference's shipped 16^3 volume, cfg/defaults.py:25, among them) and volumes that do
+                                 not divide into the bricks above; C % 4 != 0; channels-last input; and any call whose cameras / voxel
+                                 pitch make the LDS windows overflow (decided on the device).  Its backward is the plane kernel (no
+                                 global atomics, 64-bit sums where many taps meet in a pixel) for planar / quad-planar features whose
+                                 maps fit LDS, the per-tap float scatter otherwise; AUTO also prefers the plane kernel to bricks when
+                                 the volume has fewer bricks than the chip has CUs */
 } mvhmr_variant_t;
 
 typedef struct mvhmr_unproject_desc {

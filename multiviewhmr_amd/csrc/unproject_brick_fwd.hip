@@ -40,7 +40,7 @@ k_to_quad_planar_t(const TF *__restrict__ src, float4 *__restrict__ dst, int C, 
 // linearly (1-KiB runs per wave instruction instead of 128-B tile rows) and written as 512-B runs along y.
 template <typename TF>
 __global__ void __launch_bounds__(512)
-k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int H, int W, Gate gate)
+k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int H, int W, int src_aligned, Gate gate)
 {
     if (gated_off(gate)) return;
     extern __shared__ float band[];                                              // [c][y][x], row stride W | 1
@@ -51,7 +51,9 @@ k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, in
     const long long plane = (long long)H * W;
     const TF *s = src + (bv * C + q * 4) * plane + (long long)y0 * W;
     const int n = rows * W;
-    if (sizeof(TF) == 4 && (W & 3) == 0 && (plane & 3) == 0) {
+    // vector loads only from an aligned base (src_aligned: 16 B for fp32, 8 B for fp16 -- a slice of a flat buffer or a raw C-ABI
+    // pointer may start anywhere: ADVICE r03)
+    if (sizeof(TF) == 4 && (W & 3) == 0 && (plane & 3) == 0 && src_aligned) {
         // 16-B loads: 4 consecutive x of one row (W % 4 == 0 keeps them inside a row and aligned)
         for (int c = 0; c < 4; ++c)
             for (int i = threadIdx.x * 4; i < n; i += 512 * 4) {
@@ -60,7 +62,7 @@ k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, in
                 float *b = band + (c * 32 + y) * ldw + x;
                 b[0] = t.x; b[1] = t.y; b[2] = t.z; b[3] = t.w;
             }
-    } else if (sizeof(TF) == 2 && (W & 3) == 0 && (plane & 3) == 0) {
+    } else if (sizeof(TF) == 2 && (W & 3) == 0 && (plane & 3) == 0 && src_aligned) {
         // fp16 features: 8-B loads of 4 consecutive x (2-B loads ran this pass at 3.8 TB/s instead of the fp32 form's 5.9)
         for (int c = 0; c < 4; ++c)
             for (int i = threadIdx.x * 4; i < n; i += 512 * 4) {
@@ -91,8 +93,9 @@ hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p,
     const size_t band_bytes = (size_t)4 * 32 * (p.W | 1) * sizeof(float);
     if (band_bytes <= 64 * 1024) {                                               // 2+ blocks per CU
         const dim3 grid((p.H + 31) / 32, p.C / 4, p.B * p.V);
-        if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t_band<__half>, grid, dim3(512), band_bytes, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, gate);
-        else hipLaunchKernelGGL(k_to_quad_planar_t_band<float>, grid, dim3(512), band_bytes, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, gate);
+        const int aligned = (reinterpret_cast<uintptr_t>(src) % (p.feat_f16 ? 8 : 16)) == 0;
+        if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t_band<__half>, grid, dim3(512), band_bytes, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, aligned, gate);
+        else hipLaunchKernelGGL(k_to_quad_planar_t_band<float>, grid, dim3(512), band_bytes, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, aligned, gate);
         return hipGetLastError();
     }
     const dim3 grid(((p.W + 31) / 32) * ((p.H + 31) / 32), p.C / 4, p.B * p.V);

@@ -1526,3 +1526,26 @@ def test_bf16_volume_through_the_regressors_first_stage(gpu):
     # against the all-fp32 route the difference is the consumer's own bf16 arithmetic (conv inputs, BatchNorm statistics, ReLU masks)
     rel = float((grads["bf16"] - grads["fp32"]).norm() / grads["fp32"].norm())
     record_err("bf16 consumer route vs the all-fp32 route: relative L2 error of the feature gradient", rel, 0.1)
+
+
+def test_layout_pass_takes_misaligned_feature_pointers(gpu):
+    """features that are a slice of a flat buffer start at an odd element -- the layout pass must not use its 16-byte /
+    8-byte vector loads on them.  Same values, shifted storage: bit-equal results"""
+    shape = dict(B=1, V=4, C=8, H=32, W=32, vol=(8, 8, 32))
+    feats, proj, coords = _ring_problem(seed=77, **shape)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    for dt in (torch.float32, torch.float16):
+        f = torch.from_numpy(feats).to(gpu).to(dt)
+        flat = torch.empty(f.numel() + 3, device=gpu, dtype=dt)
+        outs = []
+        for off in (0, 1, 3):
+            fo = flat[off:off + f.numel()].view_as(f)
+            fo.copy_(f)
+            assert fo.is_contiguous() and fo.data_ptr() == flat.data_ptr() + off * f.element_size()
+            fo = fo.detach().requires_grad_(True)
+            out = aggregation.unprojection(fo, p, c, variant="brick")
+            out.float().sum().backward()
+            outs.append((out.detach().clone(), fo.grad.clone()))
+        for o, g in outs[1:]:
+            assert torch.equal(o, outs[0][0])
+            record_err("misaligned features (%s): gradient vs the aligned run" % str(dt), float((g.float() - outs[0][1].float()).abs().max()), 1e-3 * float(outs[0][1].float().abs().max()))
