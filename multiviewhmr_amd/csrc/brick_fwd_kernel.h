@@ -183,8 +183,11 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int BY = NT / 128, NW = NT / 64, BXK = kBX * NVOX;
-    constexpr int MAP = sizeof(TO) == 4 ? kFwdMapF32 : 0, LAY = kFwdLay;
-    constexpr int SPJ = MAP == 1 ? 4 : 1;                                        // store instructions per job
+#ifndef MVHMR_FWD_MAP16
+#define MVHMR_FWD_MAP16 1          // the lane map of 16-bit volumes: 1 = z runs + pair exchange (below), 0 = round 3's stride-4 transpose
+#endif
+    constexpr int MAP = sizeof(TO) == 4 ? kFwdMapF32 : MVHMR_FWD_MAP16, LAY = kFwdLay;
+    constexpr int SPJ = MAP == 1 ? (sizeof(TO) == 4 ? 4 : 2) : 1;                // store instructions per job
     constexpr int MC = brick_chunks_per_wave(NT);                                 // DMA chunks a wave may own per quad
     extern __shared__ __align__(16) unsigned char smem[];
     FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + lds_slots * 16);
@@ -383,7 +386,11 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         unsigned st_off[NVOX];
 #pragma unroll
         for (int u = 0; u < NVOX; ++u) {
-            if constexpr (MAP == 1) {
+            if constexpr (MAP == 1 && OSZ == 2) {
+                // 16-bit volume: lanes 2m / 2m+1 (z, z+1 of one column) exchange channel pairs; the even lane writes (z, z+1) of
+                // channels 0 / 1 as one dword each, the odd lane those of channels 2 / 3: 64-B runs per channel and column
+                st_off[u] = (vox[u] - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes;
+            } else if constexpr (MAP == 1) {
                 st_off[u] = vox[u] * OSZ;
                 if constexpr (kExp & 2048) st_off[u] &= 0x3FFFFu;
             } else {
@@ -395,7 +402,21 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             return __builtin_amdgcn_make_buffer_rsrc((kExp & 2048) ? out : base, 0, (int)(4u * chan_bytes), 0x00020000);
         };
         auto store_quad = [&](const __amdgpu_buffer_rsrc_t rs, int u, float (&res)[4]) __attribute__((always_inline)) {
-            if constexpr (MAP == 1) {
+            if constexpr (MAP == 1 && OSZ == 2) {
+                const bool odd = lane & 1;
+                const float s0 = odd ? res[0] : res[2], s1 = odd ? res[1] : res[3];     // what the partner (lane ^ 1) takes
+                const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
+                const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
+                // even lane: (own channel i at z, partner's channel i at z+1); odd lane: (partner's channel 2+i at z-1, own at z)
+                const unsigned d0 = odd ? pack2<TO>(g0, res[2]) : pack2<TO>(res[0], g0);
+                const unsigned d1 = odd ? pack2<TO>(g1, res[3]) : pack2<TO>(res[1], g1);
+                if constexpr (kExp & 8) {
+                    asm volatile("" :: "v"(d0), "v"(d1), "s"(rs));
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b32(d0, rs, (int)st_off[u], 0, kStAux);
+                    __builtin_amdgcn_raw_buffer_store_b32(d1, rs, (int)st_off[u], (int)chan_bytes, kStAux);
+                }
+            } else if constexpr (MAP == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     if constexpr (kExp & 8) asm volatile("" :: "v"(res[i]), "s"(rs));

@@ -48,6 +48,12 @@ __device__ __forceinline__ void voxel_xyz(const Coords &cs, int b, long long N, 
 
 enum : int { AGG_SOFTMAX = 0, AGG_SUM = 1, AGG_MEAN = 2, AGG_MAX = 3 };
 
+// 1 = the transcendentals of the forward's softmax are issued in runs (aggregate2); 0 = wherever the scheduler puts them
+// (the backward's aggregate_grad gains nothing from it: 12.98 vs 12.92 ms per call, round 4)
+#ifndef MVHMR_AGG_GROUP
+#define MVHMR_AGG_GROUP 1
+#endif
+
 constexpr int kWave = 64;       // CDNA wavefront
 constexpr int kMaxViews = 16;   // per-voxel view records kept in LDS / registers
 
@@ -173,9 +179,6 @@ __device__ __forceinline__ float aggregate(const float (&s)[V])
 // later the two v_rcp_f32 -- instead of wherever the scheduler drops them among the subtractions and fmas: on gfx950 a v_exp_f32
 // between plain VALU instructions costs ~2 ns more than in a run of its kind (scripts/microbench_trans.hip: 4 exp + 12 fma per
 // iteration take 31.3 ns grouped, 38.9 ns as exp, fma, fma, fma; the sum of the parts is 29.2).  Same operations, same results.
-#ifndef MVHMR_AGG_GROUP
-#define MVHMR_AGG_GROUP 1
-#endif
 template <int METHOD, int V>
 __device__ __forceinline__ void aggregate2(const float (&sa)[V], const float (&sb)[V], float &ra, float &rb)
 {
