@@ -6,7 +6,8 @@
 // (group windows: mean 2 500, max 4 000 slots at the configs[3] geometry; 29 % fewer window pixels per voxel than 4 x 4 x 32), and a
 // lane keeps one tap set and the 32 samples of its voxel: 128 VGPRs, four waves per SIMD.  The samples of both groups meet in
 // registers and go through the same aggregate2<METHOD, 8> as in k_fwd_brick: identical results.
-// Same lane map, column-major windows, stride-4 DPP transpose and stores as k_fwd_brick (brick_fwd_kernel.h).
+// Lane map, parity-split column-major windows and stores as k_fwd_brick (brick_fwd_kernel.h): fp32 volumes use the z-run map with four
+// dword stores per job, 16-bit volumes the z-run map with the pair exchange.
 #pragma once
 #include "brick_fwd_kernel.h"
 
@@ -56,6 +57,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
 {
     if (gated_off(gate)) return;
     constexpr int NT = 1024, BY = NT / 128, NW = NT / 64, VG = kGroupViews, NG = VT / VG, MC = kGroupChunks;
+    constexpr int LAY = kFwdLay, MAP = sizeof(TO) == 4 ? kFwdMapF32 : MVHMR_FWD_MAP16;
     static_assert(VT == 2 * VG, "two view groups");
     extern __shared__ __align__(16) unsigned char smem[];
     FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + lds_slots * 16);
@@ -80,7 +82,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
 
     // ---- this lane's voxel and its tap records (once per brick)
     int dcol, zin;
-    fwd_lane_voxel<0>(lane, dcol, zin);
+    fwd_lane_voxel<MAP>(lane, dcol, zin);
     const int col = wave * 2 + dcol;
     const int vx = kx * kBX + (col & 3), vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
     const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_fwd_supported)
@@ -108,7 +110,8 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     __syncthreads();
 
     // ---- window per view (block-uniform); the views of a group are packed back to back, every group starts at slot 0
-    int wx0[VT], wy0[VT], ws[VT], slot0[VT], nch[NG][VG + 1];
+    // LAY 1: the rows of a window column split by parity (brick_fwd_kernel.h): origin row even, hp half-rows, column stride 2 hp
+    int wx0[VT], wy0[VT], ws[VT], whp[VT], slot0[VT], nch[NG][VG + 1];
     int used = 0, max_stride = 0, max_chunks = 0;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -119,11 +122,18 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
             const int v = g * VG + u;
             const int xmin = uniform(sh->bbox[v][0]), ymin = uniform(sh->bbox[v][1]);
             const int xmax = uniform(sh->bbox[v][2]), ymax = uniform(sh->bbox[v][3]);
-            int bw = 0, bh = 0;
-            if (xmax >= xmin) { bw = xmax - xmin + 2; bh = ymax - ymin + 2; }
-            const int stride = bh | 1;
+            int bw = 0, stride = 1, hp = 0, y0w = ymin;
+            if constexpr (LAY == 0) {
+                int bh = 0;
+                if (xmax >= xmin) { bw = xmax - xmin + 2; bh = ymax - ymin + 2; }
+                stride = bh | 1;
+            } else {
+                y0w = ymin & ~1;
+                if (xmax >= xmin) { bw = xmax - xmin + 2; hp = (ymax + 3 - y0w) >> 1; }
+                stride = 2 * hp;
+            }
             const int chunks = (stride * bw + 63) >> 6;
-            wx0[v] = xmin; wy0[v] = ymin; ws[v] = stride;
+            wx0[v] = xmin; wy0[v] = y0w; ws[v] = stride; whp[v] = hp;
             max_stride = stride > max_stride ? stride : max_stride;
             slot0[v] = ug;
             ug += chunks << 6;
@@ -141,13 +151,24 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     if (fits) {
         for (int i = tid; i < kZeroSlots * 2; i += NT)
             *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
-        int a0[VT], ws16[VT];
+        int a0[VT], a1[LAY ? VT : 1], ws16[VT];
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
             ws16[v] = ws[v] * 16;
             const bool ok = (valid >> v) & 1u;
-            const int s0 = slot0[v] + (tx[v] - wx0[v]) * ws[v] + (ty[v] - wy0[v]);
-            a0[v] = ok ? kZeroBytes + s0 * 16 : 0;
+            if constexpr (LAY == 0) {
+                const int s0 = slot0[v] + (tx[v] - wx0[v]) * ws[v] + (ty[v] - wy0[v]);
+                a0[v] = ok ? kZeroBytes + s0 * 16 : 0;
+            } else {                                                             // even row, odd row; weights in that order (brick_fwd_kernel.h)
+                const int yr = ty[v] - wy0[v];
+                const int sc = slot0[v] + (tx[v] - wx0[v]) * ws[v];
+                a0[v] = ok ? kZeroBytes + (sc + ((yr + 1) >> 1)) * 16 : 0;
+                a1[v] = ok ? kZeroBytes + (sc + whp[v] + (yr >> 1)) * 16 : 0;
+                if (yr & 1) {
+                    const float t0 = w00[v], t1 = w01[v];
+                    w00[v] = w10[v]; w01[v] = w11[v]; w10[v] = t0; w11[v] = t1;
+                }
+            }
         }
         // ---- DMA chunks of this wave, per group: chunk c covers 64 consecutive slots of one view's window
         unsigned g_off[NG][MC];
@@ -163,12 +184,14 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
                     int u = 0;
 #pragma unroll
                     for (int uu = 1; uu < VG; ++uu) u += c >= nch[g][uu] ? 1 : 0;
-                    int sv = ws[g * VG], ox = wx0[g * VG], oy = wy0[g * VG], c0 = nch[g][0], s0 = slot0[g * VG];
+                    int sv = ws[g * VG], ox = wx0[g * VG], oy = wy0[g * VG], c0 = nch[g][0], s0 = slot0[g * VG], hv = whp[g * VG];
 #pragma unroll
                     for (int uu = 1; uu < VG; ++uu)
-                        if (u == uu) { sv = ws[g * VG + uu]; ox = wx0[g * VG + uu]; oy = wy0[g * VG + uu]; c0 = nch[g][uu]; s0 = slot0[g * VG + uu]; }
+                        if (u == uu) { sv = ws[g * VG + uu]; ox = wx0[g * VG + uu]; oy = wy0[g * VG + uu]; c0 = nch[g][uu]; s0 = slot0[g * VG + uu]; hv = whp[g * VG + uu]; }
                     const int jj = c - c0, slot = (jj << 6) + lane;
-                    const int px = slot / sv, py = slot - px * sv;
+                    const int px = slot / sv;
+                    int py = slot - px * sv;
+                    if constexpr (LAY == 1) py = py >= hv ? 2 * (py - hv) + 1 : 2 * py;
                     int gx = ox + px, gy = oy + py;
                     gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
                     gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
@@ -190,19 +213,36 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
         constexpr unsigned OSZ = sizeof(TO);
         const unsigned chan_bytes = (unsigned)(N * OSZ);
         const int z0 = ((lane >> 5) << 4) + ((lane & 3) << 2);
-        const unsigned st_off = (vox - (unsigned)zin + (unsigned)z0) * OSZ + (unsigned)((lane >> 2) & 3) * chan_bytes;
+        const unsigned st_off = MAP == 1 ? (OSZ == 4 ? vox * OSZ : (vox - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes)
+                                         : (vox - (unsigned)zin + (unsigned)z0) * OSZ + (unsigned)((lane >> 2) & 3) * chan_bytes;
         auto store_quad = [&](int q, float (&res)[4]) __attribute__((always_inline)) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
+            if constexpr (MAP == 1 && OSZ == 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rs, (int)st_off, (int)(i * chan_bytes), kStAux);
+                return;
+            } else if constexpr (MAP == 1) {                                     // 16-bit volume: pair exchange (brick_fwd_kernel.h)
+                const bool odd = lane & 1;
+                const float s0 = odd ? res[0] : res[2], s1 = odd ? res[1] : res[3];
+                const float g0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s0), 0xB1, 0xF, 0xF, false));
+                const float g1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, s1), 0xB1, 0xF, 0xF, false));
+                const unsigned d0 = odd ? pack2<TO>(g0, res[2]) : pack2<TO>(res[0], g0);
+                const unsigned d1 = odd ? pack2<TO>(g1, res[3]) : pack2<TO>(res[1], g1);
+                __builtin_amdgcn_raw_buffer_store_b32(d0, rs, (int)st_off, 0, kStAux);
+                __builtin_amdgcn_raw_buffer_store_b32(d1, rs, (int)st_off, (int)chan_bytes, kStAux);
+                return;
+            }
             stride4_transpose(res, lane);
             if constexpr (OSZ == 4) {
                 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                 const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
                                  __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
-                __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, 18);
+                __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)st_off, 0, kStAux);
             } else {
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 const u32x2 d = {pack2<TO>(res[0], res[1]), pack2<TO>(res[2], res[3])};
-                __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)st_off, 0, 18);
+                __builtin_amdgcn_raw_buffer_store_b64(d, rs, (int)st_off, 0, kStAux);
             }
         };
 
@@ -216,7 +256,9 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
         for (int q = 0; q < nq; ++q) {
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                if (g == 0 && q > 0) wait_vmcnt(1); else wait_vmcnt(0);          // g == 0: the store of quad q-1 was issued after this DMA
+                constexpr int SPJ = MAP == 1 ? (OSZ == 4 ? 4 : 2) : 1;           // store instructions per quad
+                if (g == 0 && q > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(SPJ) : "memory");   // g == 0: the stores of quad q-1 were issued after this DMA
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 bare_barrier();
                 if (g + 1 < NG) {
                     if constexpr (NG > 1) dma(q, std::integral_constant<int, (NG > 1 ? 1 : 0)>{});
@@ -230,7 +272,14 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
                     int base = a0[v] + boff;
                     asm volatile("" : "+v"(base));                               // rebuilt per use: hoisted, the 16 addresses would spill
                     const int far = base + ws16[v];
-                    const f32x4 nw = lds_tap(smem, base), sw = lds_tap(smem, base + 16), ne = lds_tap(smem, far), se = lds_tap(smem, far + 16);
+                    f32x4 nw, sw, ne, se;                                        // LAY 1: even row x0, odd row x0, even row x0+1, odd row x0+1
+                    if constexpr (LAY == 0) {
+                        nw = lds_tap(smem, base); sw = lds_tap(smem, base + 16); ne = lds_tap(smem, far); se = lds_tap(smem, far + 16);
+                    } else {
+                        int base1 = a1[v] + boff;
+                        asm volatile("" : "+v"(base1));
+                        nw = lds_tap(smem, base); sw = lds_tap(smem, base1); ne = lds_tap(smem, far); se = lds_tap(smem, base1 + ws16[v]);
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         s[i][v] = bilerp(nw.v[i], ne.v[i], sw.v[i], se.v[i], w00[v], w01[v], w10[v], w11[v]);

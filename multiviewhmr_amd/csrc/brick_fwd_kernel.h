@@ -66,6 +66,9 @@ __device__ unsigned long long g_exp_fwd_timers[8];
 #ifndef MVHMR_FWD_HP
 #define MVHMR_FWD_HP 2
 #endif
+#ifndef MVHMR_FWD_MAP16
+#define MVHMR_FWD_MAP16 1          // the lane map of 16-bit volumes: 1 = z runs + pair exchange of channel pairs, 0 = round 3's stride-4 transpose
+#endif
 constexpr int kFwdLay = MVHMR_FWD_LAY, kFwdMapF32 = MVHMR_FWD_MAP, kFwdHp = MVHMR_FWD_HP;
 constexpr int kStAux = 18;         // cache policy of the volume stores: nt | sc1 (plain 3.56 ms, sc0 3.55, sc1 3.54, nt 3.44, nt sc1 3.46: r04 ablations)
 
@@ -183,9 +186,6 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
 #endif
     constexpr int BY = NT / 128, NW = NT / 64, BXK = kBX * NVOX;
-#ifndef MVHMR_FWD_MAP16
-#define MVHMR_FWD_MAP16 1          // the lane map of 16-bit volumes: 1 = z runs + pair exchange (below), 0 = round 3's stride-4 transpose
-#endif
     constexpr int MAP = sizeof(TO) == 4 ? kFwdMapF32 : MVHMR_FWD_MAP16, LAY = kFwdLay;
     constexpr int SPJ = MAP == 1 ? (sizeof(TO) == 4 ? 4 : 2) : 1;                // store instructions per job
     constexpr int MC = brick_chunks_per_wave(NT);                                 // DMA chunks a wave may own per quad

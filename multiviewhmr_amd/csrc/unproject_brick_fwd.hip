@@ -117,7 +117,10 @@ static int fwd_threads(int V) { return V == 8 ? 512 : 1024; }          // 8 view
 // ~4 300 slots, max ~6 000 at the configs[3] geometry) overflow the 2-deep ring (4 928) for most bricks
 int brick_fwd_nvox(const Problem &p) { return (p.V <= 4 && p.X % (2 * kBX) == 0) ? 2 : 1; }
 // 8 views: 1024-thread blocks on 4 x 8 x 32 bricks with the views staged in two groups of four (brick_fwd_groups.h) when y divides
-bool brick_fwd_grouped(const Problem &p) { return p.V == 8 && p.Y % 8 == 0; }
+#ifndef MVHMR_NO_GROUPS
+#define MVHMR_NO_GROUPS 0
+#endif
+bool brick_fwd_grouped(const Problem &p) { return !MVHMR_NO_GROUPS && p.V == 8 && p.Y % 8 == 0; }
 
 bool brick_fwd_supported(const Problem &p)
 {
@@ -133,7 +136,7 @@ GateGeom brick_fwd_gate_geom(const Problem &p)
     const int nt = brick_fwd_grouped(p) ? 1024 : fwd_threads(p.V);
     GateGeom g;
     g.bx = kBX * brick_fwd_nvox(p); g.by = nt / 128; g.bz = kBZ; g.column_major = 1;
-    g.parity_rows = (!brick_fwd_grouped(p) && kFwdLay == 1) ? 1 : 0;
+    g.parity_rows = kFwdLay == 1 ? 1 : 0;
     g.view_group = brick_fwd_grouped(p) ? 4 : 0;
     g.cap_slots = fwd_cap2(fwd_lds_slots());                              // the 2-deep ring still stages through LDS
     g.max_chunks = brick_fwd_grouped(p) ? 4 * (nt / 64) : brick_chunks_per_wave(nt) * (nt / 64);
