@@ -34,7 +34,7 @@ namespace mvhmr {
 // 2 no LDS-DMA, 3 no stores, 4 no transcendentals, 5 no transpose, 6 no per-quad barrier, 7 no aggregate, 8 no wait for the DMA,
 // 9 LDS-DMA without the m0 save / restore, 10 phase timers of a brick (s_memtime, summed over all waves: mvhmr_exp_fwd_timers_read),
 // 11 stores wrapped into the first 1 MiB of the volume (they stay in L2: no HBM writes), 12 LDS-DMA sources wrapped into 128 KiB
-// (L1 / L2 hits: no miss latency)
+// (L1 / L2 hits: no miss latency), 13 only every other LDS-DMA piece, 14 only two of the four channel stores
 #ifndef MVHMR_EXP
 #define MVHMR_EXP 0
 #endif
@@ -373,7 +373,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         auto dma = [&](int roff) __attribute__((always_inline)) {
 #pragma unroll
             for (int rr = 0; rr < MC; ++rr)
-                if (rr < n_c && !(kExp & 4)) glds16_m0(src_n, g_off[rr], (unsigned)(l_dst[rr] + roff));
+                if (rr < n_c && !(kExp & 4) && !((kExp & 8192) && (rr & 1))) glds16_m0(src_n, g_off[rr], (unsigned)(l_dst[rr] + roff));
             src_n += HW;
         };
 
@@ -419,6 +419,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             } else if constexpr (MAP == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
+                    if constexpr (kExp & 16384) { if (i >= 2) { asm volatile("" :: "v"(res[i]), "s"(rs)); continue; } }
                     if constexpr (kExp & 8) asm volatile("" :: "v"(res[i]), "s"(rs));
                     else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rs, (int)st_off[u],
                                                                (kExp & 2048) ? i * 0x40000 : (int)(i * chan_bytes), (kExp & 2048) ? 0 : kStAux);
