@@ -377,7 +377,6 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             src_n += HW;
         };
 
-
         // ---- stores.  Map 1: the lane's own voxel, channel i at soffset i * chan_bytes (a wave instruction = two 128-B runs of one
         // channel plane; the TA coalesces it in 4 cycles: TA_BUFFER_COALESCED_WRITE_CYCLES).  Map 0: lane 4a+b (+16h+32g) writes
         // channel a, z = 16g + 4b .. 4b+3 of its column after the stride-4 transpose.
