@@ -234,6 +234,10 @@ int mvhmr_conv1x1_wgrad_supported(int32_t c_in, int32_t c_out, int32_t pixels);
  */
 int mvhmr_triangulate_dlt(const float *proj, const float *points, float *out, int32_t batch, int32_t views,
                           int32_t points_per_sample, void *hip_stream);
+/* the same with the per-view confidences of triangulate_point_from_multiple_views_linear_torch (utils/multiview.py:156-161: both rows of
+ * view v are multiplied by c_v before the decomposition): confidences (V) fp32 shared by the samples (confidences_per_sample = 0) or (B,V) */
+int mvhmr_triangulate_dlt_weighted(const float *proj, const float *points, const float *confidences, float *out, int32_t batch, int32_t views,
+                                   int32_t points_per_sample, int32_t confidences_per_sample, void *hip_stream);
 
 /*
  * Caller-side helper of VolumeGenerator.forward (models/aggregation.py:138-187): fills

@@ -23,7 +23,7 @@ EXPORTS = (
     "mvhmr_unproject_query_variant", "mvhmr_internal_lds_cache_key",
     "mvhmr_unproject_forward_cuboid", "mvhmr_unproject_backward_cuboid",
     "mvhmr_conv1x1_to_quad", "mvhmr_conv1x1_to_quad_supported", "mvhmr_conv1x1_planar", "mvhmr_conv1x1_planar_supported", "mvhmr_conv1x1_wgrad", "mvhmr_conv1x1_wgrad_supported", "mvhmr_unproject_query_variant_cuboid",
-    "mvhmr_unproject_backward_supported", "mvhmr_triangulate_dlt",
+    "mvhmr_unproject_backward_supported", "mvhmr_triangulate_dlt", "mvhmr_triangulate_dlt_weighted",
 )
 
 
@@ -95,6 +95,8 @@ def lib():
     L.mvhmr_internal_lds_cache_key.argtypes = [ctypes.c_int, vp]
     L.mvhmr_triangulate_dlt.restype = ctypes.c_int
     L.mvhmr_triangulate_dlt.argtypes = [vp, vp, vp, i32, i32, i32, vp]
+    L.mvhmr_triangulate_dlt_weighted.restype = ctypes.c_int
+    L.mvhmr_triangulate_dlt_weighted.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, vp]
     L.mvhmr_build_coord_volumes.restype = ctypes.c_int
     L.mvhmr_build_coord_volumes.argtypes = [vp, vp, vp, i32, i32, ctypes.POINTER(ctypes.c_double),
                                             ctypes.POINTER(ctypes.c_double), vp]

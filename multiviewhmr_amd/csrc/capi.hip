@@ -608,8 +608,17 @@ int mvhmr_triangulate_dlt(const float *proj, const float *points, float *out, in
 {
     if (!proj || !points || !out) return fail(MVHMR_ERR_INVALID_ARGUMENT, "null pointer");
     if (batch < 1 || views < 2) return fail(MVHMR_ERR_INVALID_ARGUMENT, "batch must be >= 1 and views >= 2 (got %d, %d)", batch, views);
-    return launched(launch_triangulate_dlt(proj, points, out, batch, views, points_per_sample ? 1 : 0, static_cast<hipStream_t>(hip_stream)),
+    return launched(launch_triangulate_dlt(proj, points, nullptr, out, batch, views, points_per_sample ? 1 : 0, 0, static_cast<hipStream_t>(hip_stream)),
                     "DLT triangulation");
+}
+
+int mvhmr_triangulate_dlt_weighted(const float *proj, const float *points, const float *confidences, float *out, int32_t batch, int32_t views,
+                                   int32_t points_per_sample, int32_t confidences_per_sample, void *hip_stream)
+{
+    if (!proj || !points || !confidences || !out) return fail(MVHMR_ERR_INVALID_ARGUMENT, "null pointer");
+    if (batch < 1 || views < 2) return fail(MVHMR_ERR_INVALID_ARGUMENT, "batch must be >= 1 and views >= 2 (got %d, %d)", batch, views);
+    return launched(launch_triangulate_dlt(proj, points, confidences, out, batch, views, points_per_sample ? 1 : 0, confidences_per_sample ? 1 : 0,
+                                           static_cast<hipStream_t>(hip_stream)), "weighted DLT triangulation");
 }
 
 int mvhmr_build_coord_volumes(float *coords, const float *rot, const float *center, int32_t batch, int32_t volume_size,

@@ -96,7 +96,8 @@ hipError_t launch_conv1x1_quad(const float *x, const float *w, const float *bias
                                hipStream_t s);
 
 // DLT triangulation of one point per sample (fp32 in / out, float64 inside); points (V,2) shared or (B,V,2) per sample
-hipError_t launch_triangulate_dlt(const float *proj, const float *points, float *out, int B, int V, int points_per_sample, hipStream_t s);
+hipError_t launch_triangulate_dlt(const float *proj, const float *points, const float *conf, float *out, int B, int V, int points_per_sample,
+                                  int conf_per_sample, hipStream_t s);
 
 hipError_t launch_build_coords(float *coords_out, const float *rot, const float *center, int B, int S,
                                const double pos[3], const double sides[3], hipStream_t s);

@@ -569,17 +569,20 @@ hipError_t launch_grad_cast(const float *srcT, void *dst, const Problem &p, hipS
 // normal matrix A^T A by cyclic Jacobi rotations -- no SVD, no host round trip.  cond(A) is ~10^1..10^4 for pixel-scale projection
 // matrices, its square far inside float64 (agreement with numpy's float64 SVD: tests/test_unproject_gpu.py).
 __global__ void __launch_bounds__(64)
-k_triangulate_dlt(const float *__restrict__ proj, const float *__restrict__ points, float *__restrict__ out, int B, int V, int points_per_sample)
+k_triangulate_dlt(const float *__restrict__ proj, const float *__restrict__ points, const float *__restrict__ conf, float *__restrict__ out, int B, int V,
+                  int points_per_sample, int conf_per_sample)
 {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= B) return;
     const float *P = proj + (long long)b * V * 12;
     const float *uv = points + (points_per_sample ? (long long)b * V * 2 : 0);
     double M[4][4] = {{0}}, E[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}};
+    const float *cf = conf ? conf + (conf_per_sample ? (long long)b * V : 0) : nullptr;    // A *= confidences (utils/multiview.py:156-161): rows of view v times c_v
     for (int v = 0; v < V; ++v)
         for (int r = 0; r < 2; ++r) {
             double a[4];
-            for (int k = 0; k < 4; ++k) a[k] = (double)uv[2 * v + r] * (double)P[v * 12 + 8 + k] - (double)P[v * 12 + 4 * r + k];
+            const double w = cf ? (double)cf[v] : 1.0;
+            for (int k = 0; k < 4; ++k) a[k] = w * ((double)uv[2 * v + r] * (double)P[v * 12 + 8 + k] - (double)P[v * 12 + 4 * r + k]);
             for (int i = 0; i < 4; ++i)
                 for (int j = 0; j < 4; ++j) M[i][j] += a[i] * a[j];
         }
@@ -612,9 +615,10 @@ k_triangulate_dlt(const float *__restrict__ proj, const float *__restrict__ poin
     out[3 * b + 0] = (float)(h0 / h3); out[3 * b + 1] = (float)(h1 / h3); out[3 * b + 2] = (float)(h2 / h3);
 }
 
-hipError_t launch_triangulate_dlt(const float *proj, const float *points, float *out, int B, int V, int points_per_sample, hipStream_t s)
+hipError_t launch_triangulate_dlt(const float *proj, const float *points, const float *conf, float *out, int B, int V, int points_per_sample,
+                                  int conf_per_sample, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_triangulate_dlt, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, proj, points, out, B, V, points_per_sample);
+    hipLaunchKernelGGL(k_triangulate_dlt, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, s, proj, points, conf, out, B, V, points_per_sample, conf_per_sample);
     return hipGetLastError();
 }
 

@@ -102,7 +102,7 @@ def triangulate_point_from_multiple_views_linear_torch(proj_matricies, points, c
     return homogeneous_to_euclidean((-v[:, 3]).unsqueeze(0))[0]
 
 
-def triangulate_points_from_multiple_views_linear_batch(proj_matricies, points):
+def triangulate_points_from_multiple_views_linear_batch(proj_matricies, points, confidences=None):
     """The same DLT for a whole batch at once: proj_matricies (B, V, 3, 4), points (V, 2) shared by the samples -> (B, 3),
     on proj_matricies.device with no host synchronisation (HIP tensors: mvhmr_triangulate_dlt; CPU tensors -- tests without a GPU --
     the batched float64 SVD below).  The caller (VolumeGenerator with use_triangulation, reference
@@ -118,13 +118,23 @@ def triangulate_points_from_multiple_views_linear_batch(proj_matricies, points):
         P32 = proj_matricies.detach().to(torch.float32).contiguous()
         pts32 = points.detach().to(device=P32.device, dtype=torch.float32).contiguous()
         out = torch.empty(B, 3, dtype=torch.float32, device=P32.device)
+        per_sample = 1 if pts32.dim() == 3 else 0
         with torch.cuda.device(P32.device):
-            _capi.check(L.mvhmr_triangulate_dlt(ctypes.c_void_p(P32.data_ptr()), ctypes.c_void_p(pts32.data_ptr()), ctypes.c_void_p(out.data_ptr()),
-                                                B, V, 0, ctypes.c_void_p(torch.cuda.current_stream(P32.device).cuda_stream)))
+            stream = ctypes.c_void_p(torch.cuda.current_stream(P32.device).cuda_stream)
+            if confidences is None:
+                _capi.check(L.mvhmr_triangulate_dlt(ctypes.c_void_p(P32.data_ptr()), ctypes.c_void_p(pts32.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                                    B, V, per_sample, stream))
+            else:                                                             # A *= confidences (utils/multiview.py:156-161), (V,) or (B, V)
+                c32 = confidences.detach().to(device=P32.device, dtype=torch.float32).contiguous()
+                _capi.check(L.mvhmr_triangulate_dlt_weighted(ctypes.c_void_p(P32.data_ptr()), ctypes.c_void_p(pts32.data_ptr()), ctypes.c_void_p(c32.data_ptr()),
+                                                             ctypes.c_void_p(out.data_ptr()), B, V, per_sample, 1 if c32.dim() == 2 else 0, stream))
         return out
     P = proj_matricies.to(torch.float64)
     pts = points.to(device=P.device, dtype=torch.float64)
-    A = P[:, :, 2:3].expand(B, V, 2, 4) * pts.view(1, V, 2, 1) - P[:, :, :2]
+    A = P[:, :, 2:3].expand(B, V, 2, 4) * (pts.view(B, V, 2, 1) if pts.dim() == 3 else pts.view(1, V, 2, 1)) - P[:, :, :2]
+    if confidences is not None:
+        c = confidences.to(device=P.device, dtype=torch.float64)
+        A = A * (c.view(B, V, 1, 1) if c.dim() == 2 else c.view(1, V, 1, 1))
     _, _, vh = torch.linalg.svd(A.reshape(B, 2 * V, 4), full_matrices=False)
     h = vh[:, 3, :]
     return (h[:, :3] / h[:, 3:4]).to(torch.float32)

@@ -1273,6 +1273,36 @@ def bench_projections(B, V):
     return bench.ring_projections(B, V, (96, 96), seed=5)
 
 
+def test_weighted_dlt_kernel_matches_the_reference_formulation(gpu):
+    """mvhmr_triangulate_dlt_weighted: rows of view v times c_v (utils/multiview.py:156-161) -- against the torch mirror of the reference
+    (float64 SVD of the weighted system) per sample, with per-sample points and per-sample confidences; a view with confidence 0
+    drops out (its outlier observation no longer moves the point)"""
+    rng = np.random.default_rng(21)
+    B, V = 5, 4
+    P = bench_projections(B, V)
+    X = rng.uniform(-800, 800, (B, 3))
+    hom = np.concatenate([X, np.ones((B, 1))], 1)
+    r = np.einsum("bvij,bj->bvi", P.astype(np.float64), hom)
+    uv = (r[..., :2] / r[..., 2:3] + rng.normal(0, 1.0, (B, V, 2))).astype(np.float32)
+    conf = rng.uniform(0.2, 1.0, (B, V)).astype(np.float32)
+    got = multiview.triangulate_points_from_multiple_views_linear_batch(torch.from_numpy(P).to(gpu), torch.from_numpy(uv).to(gpu), torch.from_numpy(conf).to(gpu)).cpu().numpy()
+    worst = 0.0
+    for b in range(B):
+        ref = multiview.triangulate_point_from_multiple_views_linear_torch(torch.from_numpy(P[b].astype(np.float64)), torch.from_numpy(uv[b].astype(np.float64)),
+                                                                          torch.from_numpy(conf[b].astype(np.float64))).numpy()
+        worst = max(worst, float(np.abs(got[b] - ref).max()))
+    record_err("weighted DLT kernel vs float64 SVD of the weighted system (mm)", worst, 2e-3)
+    # shared confidences (V,), one view switched off: its 300 px outlier must not matter
+    uv2 = uv.copy(); uv2[:, 2] += 300.0
+    c0 = torch.tensor([1.0, 1.0, 0.0, 1.0])
+    a = multiview.triangulate_points_from_multiple_views_linear_batch(torch.from_numpy(P).to(gpu), torch.from_numpy(uv2).to(gpu), c0.to(gpu)).cpu().numpy()
+    bb = multiview.triangulate_points_from_multiple_views_linear_batch(torch.from_numpy(P).to(gpu), torch.from_numpy(uv).to(gpu), c0.to(gpu)).cpu().numpy()
+    record_err("weighted DLT: a zero-confidence view drops out (mm)", float(np.abs(a - bb).max()), 1e-3)
+    # CPU mirror (no GPU) takes the same arguments
+    cpu = multiview.triangulate_points_from_multiple_views_linear_batch(torch.from_numpy(P), torch.from_numpy(uv), torch.from_numpy(conf)).numpy()
+    record_err("weighted DLT: device kernel vs the CPU mirror (mm)", float(np.abs(cpu - got).max()), 2e-3)
+
+
 def test_plane_backward_poisons_when_a_channel_has_only_non_finite_gradients(gpu):
     """A channel whose grad_out is NaN wherever it is not zero has no finite magnitude to scale by: its NaN contributions must still
     reach exactly their pixels (and a finite gradient so large that the int32 bound overflows fp32 is carried by the 64-bit form)"""
