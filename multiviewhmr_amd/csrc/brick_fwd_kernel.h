@@ -70,7 +70,10 @@ __device__ unsigned long long g_exp_fwd_timers[8];
 #define MVHMR_FWD_MAP16 1          // the lane map of 16-bit volumes: 1 = z runs + pair exchange of channel pairs, 0 = round 3's stride-4 transpose
 #endif
 constexpr int kFwdLay = MVHMR_FWD_LAY, kFwdMapF32 = MVHMR_FWD_MAP, kFwdHp = MVHMR_FWD_HP;
-constexpr int kStAux = 18;         // cache policy of the volume stores: nt | sc1 (plain 3.56 ms, sc0 3.55, sc1 3.54, nt 3.44, nt sc1 3.46: r04 ablations)
+#ifndef MVHMR_FWD_STAUX
+#define MVHMR_FWD_STAUX 18
+#endif
+constexpr int kStAux = MVHMR_FWD_STAUX;         // cache policy of the volume stores: nt | sc1 (plain 3.56 ms, sc0 3.55, sc1 3.54, nt 3.44, nt sc1 3.46: r04 ablations)
 
 // map 0: lane = 32 g + 16 h + 4 a + b  ->  column h of the wave's two (x-adjacent) columns, z = 16 g + 4 b + a
 // map 1: lane = 32 h + l5; lane quads of l5 -> z quads {0, 16, 20, 4, 24, 8, 12, 28} (+ lane & 3): the LDS pass groups are z runs
