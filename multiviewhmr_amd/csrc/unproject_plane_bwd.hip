@@ -103,11 +103,12 @@ inline int ds_blocks_of(const Problem &p) { return (int)((p.N + kDsThreads - 1) 
 template <int METHOD, int VT, typename TO>
 __global__ void __launch_bounds__(kDsThreads)
 k_plane_ds(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, const float4 *__restrict__ tabW, const int *__restrict__ tabX,
-           float4 *__restrict__ dsW, int *__restrict__ dsMax, int C, int H, int W, long long N, Gate gate)
+           float4 *__restrict__ dsW, int *__restrict__ dsMax, int C, int H, int W, long long N, int q0, int nqs, Gate gate)
 {
     if (gated_off(gate)) return;
+    // the stream and the maxima hold ONE slab of nqs channel quads (q0 .. q0 + nqs - 1) at a time: indices qs = q - q0 inside them
     const int nq = C >> 2, HW = H * W;
-    const int q = blockIdx.y, b = blockIdx.z;
+    const int qs = blockIdx.y, q = q0 + qs, b = blockIdx.z;
     const bool live = (long long)blockIdx.x * kDsThreads + threadIdx.x < N;
     const long long n = live ? (long long)blockIdx.x * kDsThreads + threadIdx.x : N - 1;    // tail threads redo the last voxel, store nothing
     const float4 *const fq = featK + ((long long)b * VT * nq + q) * HW;          // view v: + v * nq * HW
@@ -165,10 +166,10 @@ k_plane_ds(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, co
     float ds[4][VT];
 #pragma unroll
     for (int i = 0; i < 4; ++i) aggregate_grad<METHOD, VT>(s[i], g[i], ds[i]);
-    float4 *const dst = dsW + ((long long)b * VT * nq + q) * N + n;              // view v: + v * nq * N
+    float4 *const dst = dsW + ((long long)b * VT * nqs + qs) * N + n;            // view v: + v * nqs * N
     if (live) {
 #pragma unroll
-        for (int v = 0; v < VT; ++v) dst[(long long)v * nq * N] = make_float4(ds[0][v], ds[1][v], ds[2][v], ds[3][v]);   // plain store: the plane kernel reads it next
+        for (int v = 0; v < VT; ++v) dst[(long long)v * nqs * N] = make_float4(ds[0][v], ds[1][v], ds[2][v], ds[3][v]);   // plain store: the plane kernel reads it next
     }
     // ---- max |ds| per (view, channel) over this block's voxels (finite values only: the plane kernel marks the others), for the
     // fixed-point scales -- per VIEW: a view whose gradients are small next to another view's keeps its own resolution.  Non-negative
@@ -189,7 +190,7 @@ k_plane_ds(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, co
         int m = wmax[0][v][i];
 #pragma unroll
         for (int w = 1; w < kDsThreads / 64; ++w) m = wmax[w][v][i] > m ? wmax[w][v][i] : m;
-        dsMax[((((long long)b * nq + q) * VT + v) * gridDim.x + blockIdx.x) * 4 + i] = m;
+        dsMax[((((long long)b * nqs + qs) * VT + v) * gridDim.x + blockIdx.x) * 4 + i] = m;
     }
 }
 
@@ -216,7 +217,7 @@ template <typename TF, bool WIDE4, int COPIES, int NT>
 __global__ void __launch_bounds__(NT)
 k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int ds_blocks, const float4 *__restrict__ tabW,
             const int *__restrict__ tabX, const int *__restrict__ cmax, TF *__restrict__ grad_features, int C, int V, int H, int W, long long N,
-            Gate gate)
+            int q0, int nqs, Gate gate)
 {
     if (gated_off(gate)) return;
     constexpr int kPlaneThreads = NT;
@@ -227,8 +228,8 @@ k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int d
     unsigned *const poison = reinterpret_cast<unsigned *>(smem + (size_t)4 * cells * CELL * COPIES);   // [4][mask_words]
     PlaneShared *const sh = reinterpret_cast<PlaneShared *>(poison + 4 * mask_words);
     const int tid = threadIdx.x;
-    const int nq = C >> 2, HW = H * W;
-    const int q = blockIdx.x % nq, v_own = (blockIdx.x / nq) % V, b = blockIdx.x / (nq * V);
+    const int HW = H * W;
+    const int qs = blockIdx.x % nqs, q = q0 + qs, v_own = (blockIdx.x / nqs) % V, b = blockIdx.x / (nqs * V);   // one slab of quads per launch
     const int plane_words = 4 * cells * (CELL / 4) * COPIES;
     const int copy_off = COPIES > 1 ? ((tid >> 4) & (COPIES - 1)) * 4 * cells : 0;     // this lane group's image (8-byte cells)
 
@@ -236,12 +237,12 @@ k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int d
     if (tid < 4) sh->gmax[tid] = 0;
     __syncthreads();
 
-    const float4 *const dq = dsW + (((long long)b * V + v_own) * nq + q) * N;
+    const float4 *const dq = dsW + (((long long)b * V + v_own) * nqs + qs) * N;
     const float4 *const tw = tabW + ((long long)b * V + v_own) * N;
     const int *const tx = tabX + ((long long)b * V + v_own) * N;
     // ---- max |ds| per channel over the sample's voxels, THIS view (the Jacobian pass's per-block maxima)
     {
-        const int *const mq = dsMax + (((long long)b * nq + q) * V + v_own) * ds_blocks * 4;
+        const int *const mq = dsMax + (((long long)b * nqs + qs) * V + v_own) * ds_blocks * 4;
         int gm = 0;
         for (int k = tid >> 2; k < ds_blocks; k += kPlaneThreads >> 2) { const int m = mq[k * 4 + (tid & 3)]; gm = m > gm ? m : gm; }
         if (gm) atomicMax(&sh->gmax[tid & 3], gm);
@@ -366,42 +367,42 @@ k_bwd_plane(const float4 *__restrict__ dsW, const int *__restrict__ dsMax, int d
 
 template <int METHOD, int VT, typename TO>
 hipError_t launch_ds_instance(const float4 *featK, const TO *grad_out, const float4 *tabW, const int *tabX, float4 *dsW, int *dsMax,
-                              const Problem &p, hipStream_t s)
+                              const Problem &p, int q0, int nqs, hipStream_t s)
 {
-    const dim3 grid((unsigned)ds_blocks_of(p), (unsigned)(p.C / 4), (unsigned)p.B);
-    hipLaunchKernelGGL((k_plane_ds<METHOD, VT, TO>), grid, dim3(kDsThreads), 0, s, featK, grad_out, tabW, tabX, dsW, dsMax, p.C, p.H, p.W, p.N,
+    const dim3 grid((unsigned)ds_blocks_of(p), (unsigned)nqs, (unsigned)p.B);
+    hipLaunchKernelGGL((k_plane_ds<METHOD, VT, TO>), grid, dim3(kDsThreads), 0, s, featK, grad_out, tabW, tabX, dsW, dsMax, p.C, p.H, p.W, p.N, q0, nqs,
                        make_gate(p, false));
     return hipGetLastError();
 }
 
 template <int METHOD, typename TO>
 hipError_t launch_ds_views(const float4 *featK, const TO *go, const float4 *tabW, const int *tabX, float4 *dsW, int *dsMax, const Problem &p,
-                           hipStream_t s)
+                           int q0, int nqs, hipStream_t s)
 {
     switch (p.V) {
-    case 2: return launch_ds_instance<METHOD, 2, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
-    case 4: return launch_ds_instance<METHOD, 4, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
-    case 8: return launch_ds_instance<METHOD, 8, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
+    case 2: return launch_ds_instance<METHOD, 2, TO>(featK, go, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
+    case 4: return launch_ds_instance<METHOD, 4, TO>(featK, go, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
+    case 8: return launch_ds_instance<METHOD, 8, TO>(featK, go, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
     }
     return hipErrorNotSupported;
 }
 
 template <typename TO>
 hipError_t launch_ds_method(const float4 *featK, const TO *go, const float4 *tabW, const int *tabX, float4 *dsW, int *dsMax, const Problem &p,
-                            hipStream_t s)
+                            int q0, int nqs, hipStream_t s)
 {
     switch (p.method) {
-    case AGG_SOFTMAX: return launch_ds_views<AGG_SOFTMAX, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
-    case AGG_SUM: return launch_ds_views<AGG_SUM, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
-    case AGG_MEAN: return launch_ds_views<AGG_MEAN, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
-    case AGG_MAX: return launch_ds_views<AGG_MAX, TO>(featK, go, tabW, tabX, dsW, dsMax, p, s);
+    case AGG_SOFTMAX: return launch_ds_views<AGG_SOFTMAX, TO>(featK, go, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
+    case AGG_SUM: return launch_ds_views<AGG_SUM, TO>(featK, go, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
+    case AGG_MEAN: return launch_ds_views<AGG_MEAN, TO>(featK, go, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
+    case AGG_MAX: return launch_ds_views<AGG_MAX, TO>(featK, go, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
     }
     return hipErrorInvalidValue;
 }
 
 template <typename TF>
 hipError_t launch_plane_instance(const float4 *dsW, const int *dsMax, const float4 *tabW, const int *tabX, const int *cmax, TF *grad_features,
-                                 const Problem &p, hipStream_t s)
+                                 const Problem &p, int q0, int nqs, hipStream_t s)
 {
     const bool wide4 = plane_wide4(p.H, p.W);
     const bool copies4 = wide4 && plane_lds_bytes(p.H, p.W, 8, 4) <= (size_t)kPlaneLdsBytes / 8;   // eight blocks per CU (maps up to ~16 x 16)
@@ -409,9 +410,9 @@ hipError_t launch_plane_instance(const float4 *dsW, const int *dsMax, const floa
     auto kern = copies4 ? k_bwd_plane<TF, true, 4, 256> : wide4 ? k_bwd_plane<TF, true, 1, 1024> : k_bwd_plane<TF, false, 1, 1024>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
-    const unsigned grid = (unsigned)(p.B * p.V * (p.C / 4));
+    const unsigned grid = (unsigned)(p.B * p.V * nqs);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(copies4 ? 256 : 1024), lds, s, dsW, dsMax, ds_blocks_of(p), tabW, tabX, cmax, grad_features, p.C, p.V, p.H, p.W, p.N,
-                       make_gate(p, false));
+                       q0, nqs, make_gate(p, false));
     return hipGetLastError();
 }
 
@@ -434,13 +435,26 @@ bool plane_bwd_supported(const Problem &p)
     return true;
 }
 
-// [ weights float4 (B,V,N) | packed tap coordinates int (B,V,N) | max tap count int (B,V) | ds float4 (B,V,C/4,N) |
-//   max |ds| int4 (B, C/4, V, blocks of the Jacobian pass) ]
+// The Jacobian stream is V x the size of grad_out in fp32.  It is produced and consumed one SLAB of channel quads at a time (k_plane_ds then
+// k_bwd_plane per slab), sized to ~256 MB, so that
+// the scratch stays bounded (configs[1]: 0.27 GB instead of 1.07 GB, at +0.02 ms for the extra launches).  (A slab that fits the
+// Infinity Cache, 128 MB, is not faster: 1.303 vs 1.28 ms.)
+int plane_slab_quads(const Problem &p)
+{
+    const size_t per_quad = (size_t)p.B * p.V * (size_t)p.N * sizeof(float4);
+    size_t n = ((size_t)256 << 20) / (per_quad ? per_quad : 1);
+    if (n < 1) n = 1;
+    if (n > (size_t)(p.C / 4)) n = (size_t)(p.C / 4);
+    return (int)n;
+}
+// [ weights float4 (B,V,N) | packed tap coordinates int (B,V,N) | max tap count int (B,V) | ds float4 (B,V,slab,N) |
+//   max |ds| int4 (B, slab, V, blocks of the Jacobian pass) ]
 size_t plane_table_bytes(const Problem &p)
 {
     const size_t bvn = (size_t)p.B * p.V * (size_t)p.N;
+    const size_t slab = (size_t)plane_slab_quads(p);
     return align256(bvn * sizeof(float4)) + align256(bvn * sizeof(int)) + align256((size_t)p.B * p.V * sizeof(int)) +
-           align256(bvn * (size_t)(p.C / 4) * sizeof(float4)) + align256((size_t)p.B * (p.C / 4) * p.V * ds_blocks_of(p) * 4 * sizeof(int));
+           align256(bvn * slab * sizeof(float4)) + align256((size_t)p.B * slab * p.V * ds_blocks_of(p) * 4 * sizeof(int));
 }
 
 // featK: column-major quad-planar fp32 copy of the features; grad_features: the caller's PLANAR gradient tensor (B,V,C,Hf,Wf), every
@@ -455,21 +469,27 @@ hipError_t launch_bwd_plane(const void *featK, const void *grad_out, const float
     int *tabX = reinterpret_cast<int *>(t + align256(bvn * sizeof(float4)));
     int *cmax = reinterpret_cast<int *>(t + align256(bvn * sizeof(float4)) + align256(bvn * sizeof(int)));
     unsigned char *t3 = t + align256(bvn * sizeof(float4)) + align256(bvn * sizeof(int)) + align256((size_t)p.B * p.V * sizeof(int));
+    const int slab = plane_slab_quads(p);
     float4 *dsW = reinterpret_cast<float4 *>(t3);
-    int *dsMax = reinterpret_cast<int *>(t3 + align256(bvn * (size_t)(p.C / 4) * sizeof(float4)));
+    int *dsMax = reinterpret_cast<int *>(t3 + align256(bvn * (size_t)slab * sizeof(float4)));
     const Gate gate = make_gate(p, false);
     hipLaunchKernelGGL(k_plane_taps, dim3((unsigned)(p.B * p.V)), dim3(1024), (size_t)(p.H * p.W + 1) * sizeof(int), s, proj, coords, tabW, tabX, cmax,
                        p.V, p.H, p.W, p.N, gate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const float4 *fk = static_cast<const float4 *>(featK);
-    // the Jacobian pass (grad_out's storage type), then the planes (the gradient's storage type)
-    if (p.out_bf16) e = p.feat_f16 ? hipErrorNotSupported : launch_ds_method<bf16_t>(fk, (const bf16_t *)grad_out, tabW, tabX, dsW, dsMax, p, s);
-    else if (p.out_f16) e = launch_ds_method<__half>(fk, (const __half *)grad_out, tabW, tabX, dsW, dsMax, p, s);
-    else e = launch_ds_method<float>(fk, (const float *)grad_out, tabW, tabX, dsW, dsMax, p, s);
-    if (e != hipSuccess) return e;
-    if (p.feat_f16) return launch_plane_instance<__half>(dsW, dsMax, tabW, tabX, cmax, (__half *)grad_features, p, s);
-    return launch_plane_instance<float>(dsW, dsMax, tabW, tabX, cmax, (float *)grad_features, p, s);
+    // per slab of quads: the Jacobian pass (grad_out's storage type), then the planes (the gradient's storage type)
+    for (int q0 = 0; q0 < p.C / 4; q0 += slab) {
+        const int nqs = p.C / 4 - q0 < slab ? p.C / 4 - q0 : slab;
+        if (p.out_bf16) e = p.feat_f16 ? hipErrorNotSupported : launch_ds_method<bf16_t>(fk, (const bf16_t *)grad_out, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
+        else if (p.out_f16) e = launch_ds_method<__half>(fk, (const __half *)grad_out, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
+        else e = launch_ds_method<float>(fk, (const float *)grad_out, tabW, tabX, dsW, dsMax, p, q0, nqs, s);
+        if (e != hipSuccess) return e;
+        e = p.feat_f16 ? launch_plane_instance<__half>(dsW, dsMax, tabW, tabX, cmax, (__half *)grad_features, p, q0, nqs, s)
+                       : launch_plane_instance<float>(dsW, dsMax, tabW, tabX, cmax, (float *)grad_features, p, q0, nqs, s);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace mvhmr
