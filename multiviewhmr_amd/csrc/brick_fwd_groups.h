@@ -84,7 +84,9 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     int dcol, zin;
     fwd_lane_voxel<MAP>(lane, dcol, zin);
     const int col = wave * 2 + dcol;
-    const int vx = kx * kBX + (col & 3), vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
+    const int vx_r = kx * kBX + (col & 3), vy_r = ky * BY + (col >> 2), vz_r = kz * kBZ + zin;
+    const bool inside = vx_r < X && vy_r < Y && vz_r < Z;                           // volumes need not divide into bricks (brick_fwd_kernel.h)
+    const int vx = vx_r < X ? vx_r : X - 1, vy = vy_r < Y ? vy_r : Y - 1, vz = vz_r < Z ? vz_r : Z - 1;
     const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_fwd_supported)
     float w00[VT], w01[VT], w10[VT], w11[VT];
     int tx[VT], ty[VT];
@@ -97,10 +99,11 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
             const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
             w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
             tx[v] = t.rx0; ty[v] = t.ry0;
-            if (t.any) valid |= 1u << v;
+            const bool live = t.any && inside;
+            if (live) valid |= 1u << v;
             const int big = 1 << 30;
-            const int nxmin = wave_max_dpp(t.any ? -t.rx0 : -big), nymin = wave_max_dpp(t.any ? -t.ry0 : -big);
-            const int xmax = wave_max_dpp(t.any ? t.rx0 : -big), ymax = wave_max_dpp(t.any ? t.ry0 : -big);
+            const int nxmin = wave_max_dpp(live ? -t.rx0 : -big), nymin = wave_max_dpp(live ? -t.ry0 : -big);
+            const int xmax = wave_max_dpp(live ? t.rx0 : -big), ymax = wave_max_dpp(live ? t.ry0 : -big);
             if (lane == 0 && xmax >= -nxmin) {
                 atomicMin(&sh->bbox[v][0], -nxmin); atomicMin(&sh->bbox[v][1], -nymin);
                 atomicMax(&sh->bbox[v][2], xmax); atomicMax(&sh->bbox[v][3], ymax);
@@ -213,7 +216,9 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
         constexpr unsigned OSZ = sizeof(TO);
         const unsigned chan_bytes = (unsigned)(N * OSZ);
         const int z0 = ((lane >> 5) << 4) + ((lane & 3) << 2);
-        const unsigned st_off = MAP == 1 ? (OSZ == 4 ? vox * OSZ : (vox - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes)
+        static_assert(MAP == 1, "the stride-4 transpose map writes four z per lane: whole bricks only");
+        const unsigned st_off = !inside ? 0x80000000u                                // bit 31: beyond num_records, the stores are dropped
+                              : MAP == 1 ? (OSZ == 4 ? vox * OSZ : (vox - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes)
                                          : (vox - (unsigned)zin + (unsigned)z0) * OSZ + (unsigned)((lane >> 2) & 3) * chan_bytes;
         auto store_quad = [&](int q, float (&res)[4]) __attribute__((always_inline)) {
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
@@ -295,7 +300,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (its own function: its registers -- 8 views of
         // samples, weights and 64-bit addresses -- stay out of the fast path's allocation)
-        fwd_groups_slow<METHOD, VT, TO>(fk, obase, sh->proj, coords, b, N, vox, nq, H, W);
+        if (inside) fwd_groups_slow<METHOD, VT, TO>(fk, obase, sh->proj, coords, b, N, vox, nq, H, W);
     }
 }
 
@@ -303,7 +308,7 @@ template <int METHOD, int VT, typename TO>
 hipError_t launch_fwd_groups_instance(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s)
 {
     constexpr int NT = 1024;
-    const int nbx = p.X / kBX, nby = p.Y / (NT / 128), nbz = p.Z / kBZ;
+    const int nbx = (p.X + kBX - 1) / kBX, nby = (p.Y + NT / 128 - 1) / (NT / 128), nbz = (p.Z + kBZ - 1) / kBZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
     const int slots = fwd_lds_slots();
     const size_t lds = (size_t)slots * 16 + sizeof(FwdShared<VT>);

@@ -219,8 +219,13 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     int dcol, zin;
     fwd_lane_voxel<MAP>(lane, dcol, zin);
     const int col = wave * 2 + dcol;
-    const int vy = ky * BY + (col >> 2), vz = kz * kBZ + zin;
+    // Volumes need not divide into bricks (r04): a lane whose voxel lies outside the volume works on the clamped edge voxel's centre,
+    // takes no part in the windows (its samples read the zero region) and its stores are dropped by the buffer range check.
+    const int vy_r = ky * BY + (col >> 2), vz_r = kz * kBZ + zin;
+    const bool in_yz = vy_r < Y && vz_r < Z;
+    const int vy = vy_r < Y ? vy_r : Y - 1, vz = vz_r < Z ? vz_r : Z - 1;
     unsigned vox[NVOX];
+    bool inside[NVOX];
     float w00[NVOX][VT], w01[NVOX][VT], w10[NVOX][VT], w11[NVOX][VT];
     int tx[NVOX][VT], ty[NVOX][VT];
     unsigned valid = 0;
@@ -231,7 +236,9 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         for (int v = 0; v < VT; ++v) { bxmin[v] = big; bymin[v] = big; bxmax[v] = -big; bymax[v] = -big; }
 #pragma unroll
         for (int u = 0; u < NVOX; ++u) {
-            const int vx = kx * BXK + (col & 3) + kBX * u;
+            const int vx_r = kx * BXK + (col & 3) + kBX * u;
+            inside[u] = in_yz && vx_r < X;
+            const int vx = vx_r < X ? vx_r : X - 1;
             vox[u] = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_fwd_supported)
             float c0, c1, c2;
             voxel_xyz(coords, b, N, vox[u], c0, c1, c2);
@@ -240,7 +247,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
                 w00[u][v] = t.w00; w01[u][v] = t.w01; w10[u][v] = t.w10; w11[u][v] = t.w11;
                 tx[u][v] = t.rx0; ty[u][v] = t.ry0;
-                if (t.any) {
+                if (t.any && inside[u]) {
                     valid |= 1u << (u * VT + v);
                     bxmin[v] = t.rx0 < bxmin[v] ? t.rx0 : bxmin[v]; bxmax[v] = t.rx0 > bxmax[v] ? t.rx0 : bxmax[v];
                     bymin[v] = t.ry0 < bymin[v] ? t.ry0 : bymin[v]; bymax[v] = t.ry0 > bymax[v] ? t.ry0 : bymax[v];
@@ -391,11 +398,13 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             if constexpr (MAP == 1 && OSZ == 2) {
                 // 16-bit volume: lanes 2m / 2m+1 (z, z+1 of one column) exchange channel pairs; the even lane writes (z, z+1) of
                 // channels 0 / 1 as one dword each, the odd lane those of channels 2 / 3: 64-B runs per channel and column
-                st_off[u] = (vox[u] - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes;
+                // (Z even: a pair is inside or outside the volume as a whole)
+                st_off[u] = inside[u] ? (vox[u] - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes : 0x80000000u;
             } else if constexpr (MAP == 1) {
-                st_off[u] = vox[u] * OSZ;
+                st_off[u] = inside[u] ? vox[u] * OSZ : 0x80000000u;               // bit 31: beyond num_records, the store is dropped
                 if constexpr (kExp & 2048) st_off[u] &= 0x3FFFFu;
             } else {
+                static_assert(MAP == 1, "the stride-4 transpose map writes four z per lane: whole bricks only");
                 const int z0 = ((lane >> 5) << 4) + ((lane & 3) << 2);
                 st_off[u] = (vox[u] - (unsigned)zin + (unsigned)z0) * OSZ + (unsigned)((lane >> 2) & 3) * chan_bytes;
             }
@@ -591,8 +600,10 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                     s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[u][v], w01[u][v], w10[u][v], w11[u][v]);
                 }
                 TO *oq = obase + (long long)(q * 4) * N;
+                if (inside[u]) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) (oq + i * N)[vox[u]] = from_f32<TO>(aggregate<METHOD, VT>(s[i]));
+                    for (int i = 0; i < 4; ++i) (oq + i * N)[vox[u]] = from_f32<TO>(aggregate<METHOD, VT>(s[i]));
+                }
             }
         }
     }
@@ -604,7 +615,7 @@ int fwd_lds_slots();                                  // 16-B LDS slots of the r
 template <int METHOD, int VT, int NT, typename TO, int NVOX>
 hipError_t launch_fwd_instance(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s)
 {
-    const int nbx = p.X / (kBX * NVOX), nby = p.Y / (NT / 128), nbz = p.Z / kBZ;
+    const int nbx = (p.X + kBX * NVOX - 1) / (kBX * NVOX), nby = (p.Y + NT / 128 - 1) / (NT / 128), nbz = (p.Z + kBZ - 1) / kBZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
     const int slots = fwd_lds_slots();
     const size_t lds = (size_t)slots * 16 + sizeof(FwdShared<VT>);

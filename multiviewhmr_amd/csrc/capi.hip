@@ -94,13 +94,26 @@ size_t feat_elem(const Problem &p) { return p.feat_f16 ? 2 : 4; }
 size_t featT_bytes(const Problem &p) { return align_up((size_t)p.B * p.V * p.H * p.W * p.C4 * feat_elem(p)); }
 size_t gradT_bytes(const Problem &p) { return align_up((size_t)p.B * p.V * p.H * p.W * p.C4 * sizeof(float)); }
 
+constexpr int kChipCUs = 256;       // MI355X
+
+// AUTO prefers the brick forward only when the launch holds enough voxels to keep the chip busy: every block walks all C / 4 quads
+// whatever the volume, so one round of bricks costs the same run time however few of them there are, while the gather kernels' time
+// falls with the voxel count.  Measured break-even (profiles/r04_configs/brick_count_sweep.txt: 16^3 ... 32^3 grids, 32 ... 256
+// channels, 12 ... 96 px maps): between 64 and 108 bricks' worth of voxels; the reference's shipped 16^3 x 32 samples (64 bricks' worth,
+// half of every brick past the volume's top) runs 0.13 ms on the gather kernels against 0.21 ms.  variant = brick still forces the bricks.
+constexpr long long kBrickFwdMinVoxels = 96ll * 8 * 8 * 32;             // 96 bricks of 8 x 8 x 32
+bool brick_fwd_preferred(const Problem &p)
+{
+    return brick_fwd_supported(p) && static_cast<long long>(p.B) * p.X * p.Y * p.Z >= kBrickFwdMinVoxels;
+}
+
 // which kernel runs: channels-last input feeds the gather kernels; quad-planar input (the fused 1x1 conv's output) the brick kernels,
 // or -- through one more layout pass -- the gather kernels when the caller or the shape asks for them
 int pick_variant(const mvhmr_unproject_desc *d, const Problem &p)
 {
     if (d->feat_layout == MVHMR_LAYOUT_BVHWC) return MVHMR_VARIANT_GATHER;
     if (d->variant != MVHMR_VARIANT_AUTO) return d->variant;
-    return brick_fwd_supported(p) ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
+    return brick_fwd_preferred(p) ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
 }
 
 int variant_conflict(const mvhmr_unproject_desc *d, const Problem &p, int variant)
@@ -115,8 +128,6 @@ int variant_conflict(const mvhmr_unproject_desc *d, const Problem &p, int varian
 
 // the gradient can be accumulated straight into grad_features when that already is fp32 channels-last
 bool grad_in_place(const mvhmr_unproject_desc *d, const Problem &p) { return d->feat_layout == MVHMR_LAYOUT_BVHWC && !p.feat_f16; }
-
-constexpr int kChipCUs = 256;       // MI355X
 
 // The brick backward (window gradients accumulated in LDS in fixed point, then flushed with 256-B shaped float atomics)
 // is the default wherever the brick forward is: ~20 GB of global atomic traffic instead of the gather backward's 137 GB
@@ -154,7 +165,7 @@ bool gateable_layout(const mvhmr_unproject_desc *d, const Problem &p)
 }
 bool geometry_gated(const mvhmr_unproject_desc *d, const Problem &p)
 {
-    return d->variant == MVHMR_VARIANT_AUTO && gateable_layout(d, p) && brick_fwd_supported(p);
+    return d->variant == MVHMR_VARIANT_AUTO && gateable_layout(d, p) && brick_fwd_preferred(p);
 }
 // the backward has its own bricks and windows, hence its own gate
 bool geometry_gated_bwd(const mvhmr_unproject_desc *d, const Problem &p)
@@ -253,7 +264,7 @@ int mvhmr_unproject_query_variant(const mvhmr_unproject_desc *desc, const float 
     if (check_desc(desc, &p) != MVHMR_OK) return -1;
     const int variant = pick_variant(desc, p);
     if (variant_conflict(desc, p, variant) != MVHMR_OK) return -1;
-    if (desc->variant != MVHMR_VARIANT_AUTO || !brick_fwd_supported(p)) return variant;   // nothing to decide
+    if (desc->variant != MVHMR_VARIANT_AUTO || !brick_fwd_preferred(p)) return variant;   // nothing to decide
     if (!proj || !coords) { fail(MVHMR_ERR_INVALID_ARGUMENT, "proj / coords must be non-null"); return -1; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     int *count = nullptr, host = 0;
@@ -587,7 +598,7 @@ int mvhmr_unproject_query_variant_cuboid(const mvhmr_unproject_desc *desc, const
     if (check_desc(desc, &p) != MVHMR_OK) return -1;
     const int variant = pick_variant(desc, p);
     if (variant_conflict(desc, p, variant) != MVHMR_OK) return -1;
-    if (desc->variant != MVHMR_VARIANT_AUTO || !brick_fwd_supported(p)) return variant;
+    if (desc->variant != MVHMR_VARIANT_AUTO || !brick_fwd_preferred(p)) return variant;
     Coords cs;
     if (!proj || coords_from_cuboid(rot, center, position, sides, p, &cs) != MVHMR_OK) { fail(MVHMR_ERR_INVALID_ARGUMENT, "null pointer"); return -1; }
     hipStream_t s = static_cast<hipStream_t>(hip_stream);

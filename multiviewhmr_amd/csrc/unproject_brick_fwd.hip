@@ -115,17 +115,20 @@ int fwd_lds_slots() { return (160 * 1024 - 1024) / 16; }
 static int fwd_threads(int V) { return V == 8 ? 512 : 1024; }          // 8 views: 256 VGPRs per lane
 // 8 x 8 x 32 bricks (two voxels per lane) when x allows; 8 views keep 4 x 4 x 32: their eight windows of a doubled brick (mean
 // ~4 300 slots, max ~6 000 at the configs[3] geometry) overflow the 2-deep ring (4 928) for most bricks
-int brick_fwd_nvox(const Problem &p) { return (p.V <= 4 && p.X % (2 * kBX) == 0) ? 2 : 1; }
+// (volumes need not divide into bricks: lanes outside the volume idle.  Two voxels per lane whenever the volume is wider than one brick)
+int brick_fwd_nvox(const Problem &p) { return (p.V <= 4 && p.X > kBX) ? 2 : 1; }
 // 8 views: 1024-thread blocks on 4 x 8 x 32 bricks with the views staged in two groups of four (brick_fwd_groups.h) when y divides
 #ifndef MVHMR_NO_GROUPS
 #define MVHMR_NO_GROUPS 0
 #endif
-bool brick_fwd_grouped(const Problem &p) { return !MVHMR_NO_GROUPS && p.V == 8 && p.Y % 8 == 0; }
+bool brick_fwd_grouped(const Problem &p) { return !MVHMR_NO_GROUPS && p.V == 8; }
 
 bool brick_fwd_supported(const Problem &p)
 {
     if (p.V != 2 && p.V != 4 && p.V != 8) return false;
-    if (p.C % 4 || p.Z % kBZ || p.X % kBX || p.Y % (fwd_threads(p.V) / 128)) return false;
+    if (p.C % 4) return false;
+    // r04: any X, Y, Z -- bricks that stick out of the volume idle their outside lanes.  16-bit volumes store z pairs: Z even.
+    if ((p.out_f16 || p.out_bf16) && (p.Z & 1)) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
     if (p.N >= (1ll << 28)) return false;                                 // 32-bit byte offsets inside one quad of the output
     return true;
@@ -143,7 +146,10 @@ GateGeom brick_fwd_gate_geom(const Problem &p)
     return g;
 }
 
-int brick_count(const Problem &p, const GateGeom &g) { return (p.X / g.bx) * (p.Y / g.by) * (p.Z / g.bz) * p.B; }
+int brick_count(const Problem &p, const GateGeom &g)
+{
+    return ((p.X + g.bx - 1) / g.bx) * ((p.Y + g.by - 1) / g.by) * ((p.Z + g.bz - 1) / g.bz) * p.B;
+}
 
 // ---- geometry gate: one thread per brick projects the brick's 8 corner voxels into every view and sizes the pooled windows the
 // brick kernels would need (same arithmetic as their prologue: bbox + 2, odd line stride, 64-slot chunks).  Voxel centres are
@@ -165,7 +171,8 @@ k_brick_gate(const float *__restrict__ proj, const Coords coords, int *__restric
         float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
         bool front = true;
         for (int c = 0; c < 8; ++c) {
-            const int vx = kx * g.bx + ((c & 1) ? g.bx - 1 : 0), vy = ky * g.by + ((c & 2) ? g.by - 1 : 0), vz = kz * g.bz + ((c & 4) ? g.bz - 1 : 0);
+            int vx = kx * g.bx + ((c & 1) ? g.bx - 1 : 0), vy = ky * g.by + ((c & 2) ? g.by - 1 : 0), vz = kz * g.bz + ((c & 4) ? g.bz - 1 : 0);
+            vx = vx < X ? vx : X - 1; vy = vy < Y ? vy : Y - 1; vz = vz < Z ? vz : Z - 1;      // bricks that stick out of the volume
             float Xp[3];
             voxel_xyz(coords, b, N, ((long long)vx * Y + vy) * Z + vz, Xp[0], Xp[1], Xp[2]);
             const float a = P[0] * Xp[0] + P[1] * Xp[1] + P[2] * Xp[2] + P[3];
@@ -199,7 +206,7 @@ k_brick_gate(const float *__restrict__ proj, const Coords coords, int *__restric
 
 hipError_t launch_brick_gate(const float *proj, const Coords &coords, int *count, const GateGeom &g, const Problem &p, hipStream_t s)
 {
-    const int nbx = p.X / g.bx, nby = p.Y / g.by, nbz = p.Z / g.bz, total = nbx * nby * nbz * p.B;
+    const int nbx = (p.X + g.bx - 1) / g.bx, nby = (p.Y + g.by - 1) / g.by, nbz = (p.Z + g.bz - 1) / g.bz, total = nbx * nby * nbz * p.B;
     hipLaunchKernelGGL(k_brick_gate, dim3((total + 255) / 256), dim3(256), 0, s, proj, coords, count, p.V, p.H, p.W, p.X, p.Y, p.Z, g,
                        nbx, nby, nbz, total);
     return hipGetLastError();

@@ -77,10 +77,13 @@ def test_argument_validation_without_a_gpu():
     assert L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(d)) == 0
     assert L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(d)) == 0
     # AUTO on planar input of a shape both variants serve: one converted copy + the device-side gate counter (csrc/gate.h)
-    kw = dict(vol_x=8, vol_y=8, vol_z=32)
+    # (from 96 bricks' worth of voxels on; smaller launches go to the gather kernels without asking)
+    kw = dict(vol_x=64, vol_y=64, vol_z=32)
     fixed = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(_desc(variant=_capi.VARIANT["brick"], **kw)))
     gated = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(_desc(variant=_capi.VARIANT["auto"], **kw)))
     assert fixed > 0 and gated == fixed + 256
+    small = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(_desc(variant=_capi.VARIANT["auto"], vol_x=8, vol_y=8, vol_z=32)))
+    assert small == L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(_desc(variant=_capi.VARIANT["gather"], vol_x=8, vol_y=8, vol_z=32)))
     assert L.mvhmr_status_string(_capi.ERR_LAUNCH) == b"kernel launch failed"
 
 
