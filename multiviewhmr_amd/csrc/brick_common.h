@@ -132,7 +132,7 @@ template <int VT>
 struct BrickShared {
     int bbox[VT][4];               // xmin, ymin, xmax, ymax of the nw taps (valid voxels only)
     float proj[VT][12];
-    int aux[9];                    // backward: block-wide max |ds| per channel of the even / odd quad (float bits); [8] tap multiplicity
+    int aux[13];                   // backward: block-wide max |ds| per channel (float bits), one set of 4 per quad in flight (2 or 3); [12] tap multiplicity
 };
 
 __device__ __forceinline__ int wave_min(int x)
