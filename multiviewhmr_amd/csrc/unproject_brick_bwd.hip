@@ -167,7 +167,11 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     const int kq = (lane >> 5) * 2 + (z32 >> 4);                                  // which of the wave's four columns (BZ == 16)
     const int col = BZ == 32 ? wave * 2 + (lane >> 5) : ((wave >> 2) + (BY / 2) * (kq >> 1)) * BX + (wave & 3) + 4 * (kq & 1);
     const int zin = z32 % BZ;
-    const int vx = kx * BX + col % BX, vy = ky * BY + col / BX, vz = kz * BZ + zin;
+    // bricks past the volume's edge (extents that do not divide): such a lane idles on a clamped voxel -- no taps, zero weights, grad_out
+    // read as zero (its buffer offset carries bit 31), so it adds integer zeros to its parking words and raises no maximum
+    const int vx_raw = kx * BX + col % BX, vy_raw = ky * BY + col / BX, vz_raw = kz * BZ + zin;
+    const bool inside = vx_raw < X && vy_raw < Y && vz_raw < Z;
+    const int vx = vx_raw < X ? vx_raw : X - 1, vy = vy_raw < Y ? vy_raw : Y - 1, vz = vz_raw < Z ? vz_raw : Z - 1;
     const unsigned vox = (unsigned)(((long long)vx * Y + vy) * Z + vz);
     float w00[VT], w01[VT], w10[VT], w11[VT];
     int tx[VT], ty[VT];
@@ -183,12 +187,13 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // other axis: 13.2 instead of 13.75 ms at the north star, whose volume z axis projects onto image y; and the fused route's
             // quad-planar copy is used as it is.)
             const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
-            w00[v] = t.w00; w01[v] = t.w10; w10[v] = t.w01; w11[v] = t.w11;
+            const bool any = t.any && inside;
+            w00[v] = inside ? t.w00 : 0.f; w01[v] = inside ? t.w10 : 0.f; w10[v] = inside ? t.w01 : 0.f; w11[v] = inside ? t.w11 : 0.f;
             tx[v] = t.ry0; ty[v] = t.rx0;
-            if (t.any) valid |= 1u << v;
+            if (any) valid |= 1u << v;
             const int big = 1 << 30;
-            const int xmin = wave_min(t.any ? t.ry0 : big), ymin = wave_min(t.any ? t.rx0 : big);
-            const int xmax = wave_max(t.any ? t.ry0 : -big), ymax = wave_max(t.any ? t.rx0 : -big);
+            const int xmin = wave_min(any ? t.ry0 : big), ymin = wave_min(any ? t.rx0 : big);
+            const int xmax = wave_max(any ? t.ry0 : -big), ymax = wave_max(any ? t.rx0 : -big);
             if (lane == 0 && xmax >= xmin) {
                 atomicMin(&sh->bbox[v][0], xmin); atomicMin(&sh->bbox[v][1], ymin);
                 atomicMax(&sh->bbox[v][2], xmax); atomicMax(&sh->bbox[v][3], ymax);
@@ -227,7 +232,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     float *const gk = gradK + (long long)b * VT * nq * HW * 4;
     const TO *const gobase = grad_out + (long long)b * C * N;
     const unsigned chan_bytes = (unsigned)(N * 4);
-    const unsigned voxb = vox * 4u;
+    const unsigned voxb = inside ? vox * 4u : 0x80000000u;                       // beyond num_records: the load returns 0
 
     if (fits) {
         for (int i = tid; i < kZeroSlots * NBUF; i += NT)
@@ -297,7 +302,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             } else {                                                             // fp16 storage: 64-B runs per channel
                 const TO *gp = gobase + (long long)(q * 4) * N + vox;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gn[i] = to_f32<TO>(gp[(long long)i * N]);
+                for (int i = 0; i < 4; ++i) gn[i] = inside ? to_f32<TO>(gp[(long long)i * N]) : 0.f;
             }
         };
         auto load_g = [&](int q) __attribute__((always_inline)) { load_g_to(q, gn); };
@@ -629,7 +634,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     } else {
         // ---- windows do not fit: scatter straight to the accumulator (its own function: keeps its registers -- 16 tap
         // offsets on top of the weights -- out of the fast path's allocation, which otherwise spills in the quad loop)
-        bwd_brick_slow<METHOD, VT, TO>(fk, gobase, gk, sh->proj, c0, c1, c2, vox, N, nq, H, W);
+        if (inside) bwd_brick_slow<METHOD, VT, TO>(fk, gobase, gk, sh->proj, c0, c1, c2, vox, N, nq, H, W);
     }
 }
 
@@ -671,8 +676,14 @@ constexpr int kNTb8 = 512;                            // 8 views: 4 x 4 x 32 bri
 // 32-B runs: still hidden, 18.1 -> 15.1 ms like fp32), 4 x BY x 32 otherwise
 int bwd_brick_z(const Problem &p)
 {
-    const int by = (p.V == 8 || (kExpB & 128)) ? 4 : 8;
-    return (p.X % 8 == 0 && p.Y % by == 0 && p.Z % 16 == 0) ? 16 : kBZ;
+    const int by = (p.V == 8 || (kExpB & 128)) ? 4 : 8, nt = p.V == 8 ? kNTb8 : kNTb;
+    if (p.X % 8 == 0 && p.Y % by == 0 && p.Z % 16 == 0) return 16;
+    const int by32 = nt / 128;
+    if (p.X % kBX == 0 && p.Y % by32 == 0 && p.Z % kBZ == 0) return kBZ;
+    // neither shape divides the volume: the one whose bricks cover it with fewer idle lanes
+    auto cover = [](int n, int b) { return (long long)((n + b - 1) / b) * b; };
+    const long long c16 = cover(p.X, 8) * cover(p.Y, by) * cover(p.Z, 16), c32 = cover(p.X, kBX) * cover(p.Y, by32) * cover(p.Z, kBZ);
+    return c16 <= c32 ? 16 : kBZ;
 }
 
 template <int METHOD, int VT, int NT, typename TO, int BZ = kBZ>
@@ -680,7 +691,7 @@ hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj,
                      hipStream_t s)
 {
     constexpr int BX = bwd_brick_x(BZ), BY = NT / (BZ * BX);
-    const int nbx = p.X / BX, nby = p.Y / BY, nbz = p.Z / BZ;
+    const int nbx = (p.X + BX - 1) / BX, nby = (p.Y + BY - 1) / BY, nbz = (p.Z + BZ - 1) / BZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
     const int lds_bytes = bwd_lds_bytes(NT, VT);
     const size_t lds = (size_t)lds_bytes + sizeof(BrickShared<VT>);
@@ -758,9 +769,7 @@ bool brick_bwd_supported(const Problem &p)
 {
     if (p.feat_f16 != p.out_f16) return false;                            // fp32 or fp16 storage throughout (or fp32 features with a bf16 volume); other mixes -> gather
     if (p.V != 2 && p.V != 4 && p.V != 8) return false;
-    const int nt = p.V == 8 ? kNTb8 : kNTb;
     if (p.C % 4) return false;
-    if (bwd_brick_z(p) != 16 && (p.Z % kBZ || p.X % kBX || p.Y % (nt / 128))) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
     if ((long long)p.V * (p.C / 4) * p.H * p.W >= (1ll << 27)) return false;   // one sample's accumulator: 32-bit byte offsets (buffer atomics)
     if (p.N >= (1ll << 28)) return false;

@@ -67,12 +67,8 @@ def run(seed=1, cases=60, big=False, dtype="f32", verbose=True):
                 raise
             assert out.dtype == tdt
             e1 = err(out.detach().float().cpu().numpy(), ref) / (bound(ref) + ulp * float(np.abs(ref).max()))
-            try:
-                out.backward(torch.from_numpy(go).to(gpu).to(tdt))
-                e2 = err(f.grad.float().cpu().numpy(), gref) / (bound(gref) + gulp * float(np.abs(gref).max()))
-            except RuntimeError:
-                if variant != "brick": raise
-                e2 = 0.0                                                            # the brick BACKWARD needs whole bricks (the forward does not): forward checked only
+            out.backward(torch.from_numpy(go).to(gpu).to(tdt))
+            e2 = err(f.grad.float().cpu().numpy(), gref) / (bound(gref) + gulp * float(np.abs(gref).max()))
             n += 1
             if max(e1, e2) > worst:
                 worst = max(e1, e2); verbose and print("case %d %s V%d C%d %dx%d vol%s %s: fwd %.3g bwd %.3g of the bound" % (case, variant, V, C, H, W, (X, Y, Z), mode, e1, e2), flush=True)

@@ -211,6 +211,10 @@ def test_brick_softmax_over_the_whole_float_range(views, gpu):
     dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views, overflow: out-of-line path
     dict(B=1, V=4, C=8, H=24, W=40, vol=(8, 8, 32)),          # non-square maps (column-major windows), W not a multiple of the 32-column gradient band
     dict(B=1, V=2, C=8, H=136, W=20, vol=(8, 8, 32)),         # tall maps: the gradient layout pass falls back to 8-column bands
+    dict(B=2, V=4, C=8, H=24, W=24, vol=(9, 7, 13)),          # extents that do not divide into bricks: 8 x 8 x 16 bricks, outside lanes idle
+    dict(B=1, V=4, C=8, H=32, W=32, vol=(12, 20, 40)),        # ragged in all three axes, several bricks per axis
+    dict(B=1, V=8, C=8, H=24, W=24, vol=(6, 10, 33)),         # 8 views, ragged (8 x 4 x 16 bricks)
+    dict(B=1, V=2, C=8, H=24, W=24, vol=(4, 8, 33)),          # ragged in z only: the 4 x 8 x 32 bricks cover it with fewer idle lanes
 ])
 @pytest.mark.parametrize("mode", MODES)
 def test_brick_backward_vs_oracle(shape, mode, gpu):
