@@ -10,6 +10,12 @@ constexpr int kBX = 4;
 constexpr int kMaxChunks = 5;      // 64-slot DMA chunks per wave per quad (1024-thread bricks)
 // 512-thread bricks (8 views) have half the waves for up to twice the window slots
 constexpr int brick_chunks_per_wave(int nt) { return nt >= 1024 ? kMaxChunks : 2 * kMaxChunks; }
+// View counts between the compiled ones run the next larger kernel with the missing views ABSENT (brick kernels: 2, 4, 8 view slots):
+// an absent view has no camera and no window; where the aggregate needs it out of the way (softmax, max) its samples read
+// kAbsentSample from slot kAbsentSlot of the always-zero head of every LDS ring buffer (its neighbours stay zero).
+constexpr int brick_view_slots(int v) { return v <= 2 ? 2 : v <= 4 ? 4 : 8; }
+constexpr int kAbsentSlot = 64;
+constexpr float kAbsentSample = -3.4028234663852886e38f;                        // -FLT_MAX: exp(that - m) = 0, 0 * that = -0, never a maximum
 constexpr int kZeroSlots = 128;    // always-zero 16-B slots at the head of every ring buffer (row stride <= 126)
 constexpr int kZeroBytes = kZeroSlots * 16;
 

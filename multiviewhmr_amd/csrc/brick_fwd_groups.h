@@ -19,8 +19,10 @@ constexpr int kGroupChunks = 4;                       // DMA chunks a wave may o
 // one voxel sampled straight from global memory: taps rebuilt from the projection (clamped taps, zero weights outside)
 template <int METHOD, int VT, typename TO>
 __device__ __attribute__((noinline)) void fwd_groups_slow(const float4 *fk, TO *obase, const float (*proj)[12], const Coords &coords, int b,
-                                                          long long N, unsigned vox, int nq, int H, int W)
+                                                          long long N, unsigned vox, int nq, int H, int W, int nv)
 {
+    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
     const int HW = H * W;
     float c0, c1, c2;
     voxel_xyz(coords, b, N, vox, c0, c1, c2);
@@ -30,7 +32,7 @@ __device__ __attribute__((noinline)) void fwd_groups_slow(const float4 *fk, TO *
     for (int v = 0; v < VT; ++v) {
         const Taps t = make_taps(proj[v], c0, c1, c2, H, W);
         w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
-        const int base = (v * nq) * HW;
+        const int base = ((v < nv ? v : 0) * nq) * HW;                          // an absent view reads view 0's pixels (and discards them)
         o00[v] = base + t.x0 * H + t.y0; o01[v] = base + t.x1 * H + t.y0; o10[v] = base + t.x0 * H + t.y1; o11[v] = base + t.x1 * H + t.y1;
     }
     for (int q = 0; q < nq; ++q) {
@@ -43,18 +45,27 @@ __device__ __attribute__((noinline)) void fwd_groups_slow(const float4 *fk, TO *
             s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[v], w01[v], w10[v], w11[v]);
             s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]);
             s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]);
+            if (v >= nv) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i][v] = kAbsentReads ? kAbsentSample : 0.f;
+            }
         }
         TO *oq = obase + (long long)(q * 4) * N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) (oq + i * N)[vox] = from_f32<TO>(aggregate<METHOD, VT>(s[i]));
+        for (int i = 0; i < 4; ++i) {
+            float r = aggregate<METHOD, VT>(s[i]);
+            if constexpr (METHOD == AGG_MEAN) r *= mean_fix;
+            (oq + i * N)[vox] = from_f32<TO>(r);
+        }
     }
 }
 
 template <int METHOD, int VT, typename TO>
 __global__ void __launch_bounds__(1024)
 k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords, TO *__restrict__ out, int C,
-                   int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample, int lds_slots, int total_blocks, Gate gate)
+                   int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample, int lds_slots, int total_blocks, int nv, Gate gate)
 {
+    // nv <= VT real views (5 ... 7 views run this kernel): the others are absent, as in k_fwd_brick
     if (gated_off(gate)) return;
     constexpr int NT = 1024, BY = NT / 128, NW = NT / 64, VG = kGroupViews, NG = VT / VG, MC = kGroupChunks;
     constexpr int LAY = kFwdLay, MAP = sizeof(TO) == 4 ? kFwdMapF32 : MVHMR_FWD_MAP16;
@@ -76,7 +87,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     const long long N = (long long)X * Y * Z;
     const int HW = H * W, nq = C >> 2;
 
-    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = proj[((long long)b * VT) * 12 + tid];
+    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
     if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
     __syncthreads();
 
@@ -99,7 +110,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
             const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
             w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
             tx[v] = t.rx0; ty[v] = t.ry0;
-            const bool live = t.any && inside;
+            const bool live = t.any && inside && v < nv;
             if (live) valid |= 1u << v;
             const int big = 1 << 30;
             const int nxmin = wave_max_dpp(live ? -t.rx0 : -big), nymin = wave_max_dpp(live ? -t.ry0 : -big);
@@ -149,11 +160,15 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     const int buf_bytes = kZeroBytes + cap * 16;
     const bool fits = used <= cap && max_chunks <= MC * NW && max_stride + 2 <= kZeroSlots;
     TO *const obase = out + (long long)b * C * N;
-    const float4 *const fk = featK + (long long)b * VT * nq * HW;
+    const float4 *const fk = featK + (long long)b * nv * nq * HW;
+    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
 
     if (fits) {
-        for (int i = tid; i < kZeroSlots * 2; i += NT)
-            *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < kZeroSlots * 2; i += NT) {
+            const float z = (kAbsentReads && nv < VT && i % kZeroSlots == kAbsentSlot) ? kAbsentSample : 0.f;
+            *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(z, z, z, z);
+        }
         int a0[VT], a1[LAY ? VT : 1], ws16[VT];
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
@@ -171,6 +186,12 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
                     const float t0 = w00[v], t1 = w01[v];
                     w00[v] = w10[v]; w01[v] = w11[v]; w10[v] = t0; w11[v] = t1;
                 }
+            }
+            if (kAbsentReads && v >= nv) {                                       // the absent view's one "tap": kAbsentSample, weight 1
+                a0[v] = kAbsentSlot * 16;
+                if constexpr (LAY != 0) a1[v] = kAbsentSlot * 16;
+                ws16[v] = 16;
+                w00[v] = 1.f; w01[v] = 0.f; w10[v] = 0.f; w11[v] = 0.f;
             }
         }
         // ---- DMA chunks of this wave, per group: chunk c covers 64 consecutive slots of one view's window
@@ -294,13 +315,16 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
             }
             float res[4];
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) aggregate2<METHOD, VT>(s[i], s[i + 1], res[i], res[i + 1]);
+            for (int i = 0; i < 4; i += 2) {
+                aggregate2<METHOD, VT>(s[i], s[i + 1], res[i], res[i + 1]);
+                if constexpr (METHOD == AGG_MEAN) { res[i] *= mean_fix; res[i + 1] *= mean_fix; }
+            }
             store_quad(q, res);
         }
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (its own function: its registers -- 8 views of
         // samples, weights and 64-bit addresses -- stay out of the fast path's allocation)
-        if (inside) fwd_groups_slow<METHOD, VT, TO>(fk, obase, sh->proj, coords, b, N, vox, nq, H, W);
+        if (inside) fwd_groups_slow<METHOD, VT, TO>(fk, obase, sh->proj, coords, b, N, vox, nq, H, W, nv);
     }
 }
 
@@ -317,7 +341,7 @@ hipError_t launch_fwd_groups_instance(const float4 *featK, const float *proj, co
     if (e != hipSuccess) return e;
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
     const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, make_gate(p, true));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, p.V, make_gate(p, true));
     return hipGetLastError();
 }
 

@@ -145,7 +145,7 @@ __device__ __forceinline__ float fwd_aggregate(const float (&s)[VT])
 
 // aggregate2<> behind the timing-only ablations
 template <int METHOD, int VT>
-__device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const float (&sb)[VT], float &ra, float &rb)
+__device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const float (&sb)[VT], float &ra, float &rb, float mean_fix)
 {
     if constexpr (kExp & (16 | 128)) {
         ra = fwd_aggregate<METHOD, VT>(sa);
@@ -153,6 +153,7 @@ __device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const floa
     } else {
         aggregate2<METHOD, VT>(sa, sb, ra, rb);
     }
+    if constexpr (METHOD == AGG_MEAN) { ra *= mean_fix; rb *= mean_fix; }          // VT / nv (1 when every view is real: exact)
 }
 
 // s_waitcnt vmcnt(K + n) with an immediate for a wave-uniform n in 0 .. MAXI, tried from the likely end (a wave owns most of its MAXI
@@ -182,8 +183,11 @@ template <int METHOD, int VT, int NT, typename TO, int NVOX>
 __global__ void __launch_bounds__(NT)
 k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords,
             TO *__restrict__ out, int C, int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample,
-            int lds_slots, int total_blocks, Gate gate)
+            int lds_slots, int total_blocks, int nv, Gate gate)
 {
+    // nv <= VT views are real (3 views run the 4-view kernel): the others have no camera, no window and no part in the aggregate --
+    // their samples read kAbsentSample from a slot of the zero region (softmax weight exp(-FLT_MAX - m) = 0, never the maximum) or
+    // plain zeros (sum; mean, which is rescaled by VT / nv)
     if (gated_off(gate)) return;
 #if MVHMR_EXP & 1024
     unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
@@ -211,7 +215,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     const long long N = (long long)X * Y * Z;
     const int HW = H * W, nq = C >> 2;
 
-    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = proj[((long long)b * VT) * 12 + tid];
+    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
     if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
     __syncthreads();
 
@@ -247,7 +251,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
                 w00[u][v] = t.w00; w01[u][v] = t.w01; w10[u][v] = t.w10; w11[u][v] = t.w11;
                 tx[u][v] = t.rx0; ty[u][v] = t.ry0;
-                if (t.any && inside[u]) {
+                if (t.any && inside[u] && v < nv) {
                     valid |= 1u << (u * VT + v);
                     bxmin[v] = t.rx0 < bxmin[v] ? t.rx0 : bxmin[v]; bxmax[v] = t.rx0 > bxmax[v] ? t.rx0 : bxmax[v];
                     bymin[v] = t.ry0 < bymin[v] ? t.ry0 : bymin[v]; bymax[v] = t.ry0 > bymax[v] ? t.ry0 : bymax[v];
@@ -313,11 +317,15 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     const int buf_bytes = kZeroBytes + cap * 16;
     const bool fits = used <= cap && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots;
     TO *const obase = out + (long long)b * C * N;
-    const float4 *const fk = featK + (long long)b * VT * nq * HW;
+    const float4 *const fk = featK + (long long)b * nv * nq * HW;
+    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;    // absent views sample kAbsentSample (else zeros)
+    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
 
     if (fits) {
-        for (int i = tid; i < kZeroSlots * nb; i += NT)
-            *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < kZeroSlots * nb; i += NT) {
+            const float z = (kAbsentReads && nv < VT && i % kZeroSlots == kAbsentSlot) ? kAbsentSample : 0.f;
+            *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(z, z, z, z);
+        }
         // ---- LDS byte offsets (inside a buffer) of the taps in column x0; column x0 + 1 is one stride further.  A sample that is
         // identically zero reads the zero region at the head of the buffer (long enough for "one stride further").
         // LAY 0: a0 = the nw tap, sw 16 B further.  LAY 1: a0 = the EVEN row of the footprint, a1 = the odd row, and the weights are
@@ -344,7 +352,13 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                     }
                 }
                 if constexpr (kExp & 1) a0[u][v] = kZeroBytes + (lane + 64 * v + 256 * u) * 16;
+                if (kAbsentReads && v >= nv) {                                   // wave-uniform: the absent view's one "tap"
+                    a0[u][v] = kAbsentSlot * 16;
+                    if constexpr (LAY != 0) a1[u][v] = kAbsentSlot * 16;
+                    w00[u][v] = 1.f; w01[u][v] = 0.f; w10[u][v] = 0.f; w11[u][v] = 0.f;
+                }
             }
+            if (kAbsentReads && v >= nv) ws16[v] = 16;                           // "one stride further": the zero slot next to it
         }
         // ---- DMA chunks of this wave: chunk c covers 64 consecutive slots of one view's window; the wave owns chunks wave,
         // wave + NW, ...: rr < n_c of its MC slots
@@ -525,12 +539,12 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 read_view(r0, u, 0, 0);
                 if constexpr (VT > 1) read_view(r0, u, 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
-                fwd_aggregate2<METHOD, VT>(prev[0], prev[1], res[0], res[1]);
+                fwd_aggregate2<METHOD, VT>(prev[0], prev[1], res[0], res[1], mean_fix);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int v = 0; v < VT; ++v) {
                     if (v == (VT + 1) / 2) {
-                        fwd_aggregate2<METHOD, VT>(prev[2], prev[3], res[2], res[3]);
+                        fwd_aggregate2<METHOD, VT>(prev[2], prev[3], res[2], res[3], mean_fix);
                         if (u > 0) store_quad(rs_cur, u - 1, res);
                         else if (q > 0) store_quad(rs_prev, NVOX - 1, res);
                         __builtin_amdgcn_sched_barrier(0);
@@ -565,8 +579,8 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         const bool last_in_sp = ((NVOX & 1) ? nq - 1 : NVOX - 1) & 1;
 #pragma unroll
         for (int c = 0; c < 4; c += 2) {
-            if (last_in_sp) fwd_aggregate2<METHOD, VT>(sp[c], sp[c + 1], res[c], res[c + 1]);
-            else fwd_aggregate2<METHOD, VT>(sq[c], sq[c + 1], res[c], res[c + 1]);
+            if (last_in_sp) fwd_aggregate2<METHOD, VT>(sp[c], sp[c + 1], res[c], res[c + 1], mean_fix);
+            else fwd_aggregate2<METHOD, VT>(sq[c], sq[c + 1], res[c], res[c + 1], mean_fix);
         }
         store_quad(rs_prev, NVOX - 1, res);
         EXP_FT(4);                                                               // the quad loop
@@ -585,7 +599,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             for (int v = 0; v < VT; ++v) {
                 const int x0 = tx[u][v] < 0 ? 0 : tx[u][v], y0 = ty[u][v] < 0 ? 0 : ty[u][v];
                 const int x1 = tx[u][v] + 1 > W - 1 ? W - 1 : tx[u][v] + 1, y1 = ty[u][v] + 1 > H - 1 ? H - 1 : ty[u][v] + 1;
-                const int base = (v * nq) * HW;
+                const int base = ((v < nv ? v : 0) * nq) * HW;                  // an absent view reads view 0's pixels (and discards them)
                 o00[v] = base + x0 * H + y0; o01[v] = base + x1 * H + y0; o10[v] = base + x0 * H + y1; o11[v] = base + x1 * H + y1;
             }
             for (int q = 0; q < nq; ++q) {
@@ -598,11 +612,19 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                     s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[u][v], w01[u][v], w10[u][v], w11[u][v]);
                     s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[u][v], w01[u][v], w10[u][v], w11[u][v]);
                     s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[u][v], w01[u][v], w10[u][v], w11[u][v]);
+                    if (v >= nv) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s[i][v] = kAbsentReads ? kAbsentSample : 0.f;
+                    }
                 }
                 TO *oq = obase + (long long)(q * 4) * N;
                 if (inside[u]) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) (oq + i * N)[vox[u]] = from_f32<TO>(aggregate<METHOD, VT>(s[i]));
+                    for (int i = 0; i < 4; ++i) {
+                        float r = aggregate<METHOD, VT>(s[i]);
+                        if constexpr (METHOD == AGG_MEAN) r *= mean_fix;
+                        (oq + i * N)[vox[u]] = from_f32<TO>(r);
+                    }
                 }
             }
         }
@@ -624,7 +646,8 @@ hipError_t launch_fwd_instance(const float4 *featK, const float *proj, const Coo
     if (e != hipSuccess) return e;
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
     const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;   // tile work items x 8 XCDs x samples
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, make_gate(p, true));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, p.V,
+                       make_gate(p, true));
     return hipGetLastError();
 }
 
@@ -639,7 +662,7 @@ hipError_t launch_fwd_method(const void *featK_, const float *proj, const Coords
 {
     const float4 *featK = static_cast<const float4 *>(featK_);
 #define MVHMR_FWD_CASE(NVIEWS, NTHR, NV)                                                                                                 \
-    if (p.V == NVIEWS && nvox == NV)                                                                                                      \
+    if (brick_view_slots(p.V) == NVIEWS && nvox == NV)                                                                                                   \
         return p.out_f16    ? launch_fwd_instance<METHOD, NVIEWS, NTHR, __half, NV>(featK, proj, coords, (__half *)out, p, s)            \
                : p.out_bf16 ? launch_fwd_instance<METHOD, NVIEWS, NTHR, bf16_t, NV>(featK, proj, coords, (bf16_t *)out, p, s)            \
                             : launch_fwd_instance<METHOD, NVIEWS, NTHR, float, NV>(featK, proj, coords, (float *)out, p, s)

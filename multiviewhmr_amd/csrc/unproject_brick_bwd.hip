@@ -88,9 +88,11 @@ constexpr int kAuxCmax = 12;       // BrickShared::aux word of the tap multiplic
 // Slow path of k_bwd_brick for one voxel: global float atomics per tap (bricks whose windows do not fit the LDS pool).
 template <int METHOD, int VT, typename TO>
 __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const TO *gobase, float *gk, const float (*proj)[12],
-                                                         float c0, float c1, float c2, unsigned vox, long long N, int nq, int H, int W)
+                                                         float c0, float c1, float c2, unsigned vox, long long N, int nq, int H, int W, int nv)
 {
     const int HW = H * W;
+    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
     float w00[VT], w01[VT], w10[VT], w11[VT];
     int o00[VT], o01[VT], o10[VT], o11[VT];
 #pragma unroll
@@ -99,7 +101,7 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
         w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
         const int x0 = t.rx0 < 0 ? 0 : t.rx0, y0 = t.ry0 < 0 ? 0 : t.ry0;
         const int x1 = t.rx0 + 1 > W - 1 ? W - 1 : t.rx0 + 1, y1 = t.ry0 + 1 > H - 1 ? H - 1 : t.ry0 + 1;
-        const int base = (v * nq) * HW;
+        const int base = ((v < nv ? v : 0) * nq) * HW;                          // an absent view reads view 0's pixels (and discards them)
         o00[v] = base + x0 * H + y0; o01[v] = base + x1 * H + y0; o10[v] = base + x0 * H + y1; o11[v] = base + x1 * H + y1;   // column-major copy
     }
     for (int q = 0; q < nq; ++q) {
@@ -113,14 +115,20 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
             s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[v], w01[v], w10[v], w11[v]);
             s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]);
             s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]);
+            if (v >= nv) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i][v] = kAbsentReads ? kAbsentSample : 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const float g = to_f32<TO>(gobase[(long long)(q * 4 + i) * N + vox]);
+            float g = to_f32<TO>(gobase[(long long)(q * 4 + i) * N + vox]);
+            if constexpr (METHOD == AGG_MEAN) g *= mean_fix;
             float ds[VT];
             aggregate_grad<METHOD, VT>(s[i], g, ds);
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
+                if (v >= nv) continue;                                           // absent view: nothing to receive
                 if (w00[v] != 0.f) atomicAdd(gq + (long long)o00[v] * 4 + i, ds[v] * w00[v]);
                 if (w01[v] != 0.f) atomicAdd(gq + (long long)o01[v] * 4 + i, ds[v] * w01[v]);
                 if (w10[v] != 0.f) atomicAdd(gq + (long long)o10[v] * 4 + i, ds[v] * w10[v]);
@@ -134,8 +142,10 @@ template <int METHOD, int VT, int NT, typename TO, int BZ>
 __global__ void __launch_bounds__(NT, ((kExpB & 128) && NT == 512 && VT <= 4) ? 4 : 1)
 k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, const float *__restrict__ proj,
             const Coords coords, float *__restrict__ gradK, int C, int H, int W, int X, int Y, int Z, int nby,
-            int nbz, int bricks_per_sample, int lds_bytes, int total_blocks, Gate gate)
+            int nbz, int bricks_per_sample, int lds_bytes, int total_blocks, int nv, Gate gate)
 {
+    // nv <= VT real views (3 views run the 4-view kernel, 5 ... 7 the 8-view one): an absent view has no camera and no window; for
+    // softmax / max its samples read kAbsentSample from the zero head of the feature buffers (brick_common.h), its ds is forced to zero
     if (gated_off(gate)) return;
     // brick = BX x BY x BZ voxels, one per lane; a wave holds 64 / BZ whole z columns
     constexpr int BX = bwd_brick_x(BZ), BY = NT / (BZ * BX), NW = NT / 64, CW = 64 / BZ;
@@ -155,7 +165,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     const long long N = (long long)X * Y * Z;
     const int HW = H * W, nq = C >> 2;
 
-    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = proj[((long long)b * VT) * 12 + tid];
+    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
     if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
     __syncthreads();
 
@@ -187,7 +197,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // other axis: 13.2 instead of 13.75 ms at the north star, whose volume z axis projects onto image y; and the fused route's
             // quad-planar copy is used as it is.)
             const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
-            const bool any = t.any && inside;
+            const bool any = t.any && inside && v < nv;
             w00[v] = inside ? t.w00 : 0.f; w01[v] = inside ? t.w10 : 0.f; w10[v] = inside ? t.w01 : 0.f; w11[v] = inside ? t.w11 : 0.f;
             tx[v] = t.ry0; ty[v] = t.rx0;
             if (any) valid |= 1u << v;
@@ -228,15 +238,19 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     constexpr int plane_floats = kZeroSlots + cap + kPlanePad;
     int *const iplanes = reinterpret_cast<int *>(smem + NBUF * buf_bytes);
     const bool fits = used <= cap && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots;
-    const float4 *const fk = featK + (long long)b * VT * nq * HW;
-    float *const gk = gradK + (long long)b * VT * nq * HW * 4;
+    const float4 *const fk = featK + (long long)b * nv * nq * HW;
+    float *const gk = gradK + (long long)b * nv * nq * HW * 4;
+    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
     const TO *const gobase = grad_out + (long long)b * C * N;
     const unsigned chan_bytes = (unsigned)(N * 4);
     const unsigned voxb = inside ? vox * 4u : 0x80000000u;                       // beyond num_records: the load returns 0
 
     if (fits) {
-        for (int i = tid; i < kZeroSlots * NBUF; i += NT)
-            *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = tid; i < kZeroSlots * NBUF; i += NT) {
+            const float z = (kAbsentReads && nv < VT && i % kZeroSlots == kAbsentSlot) ? kAbsentSample : 0.f;
+            *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(z, z, z, z);
+        }
         for (int i = tid; i < PSETS * 4 * plane_floats; i += NT) iplanes[i] = 0;
         if (tid < 13) sh->aux[tid] = 0;
 
@@ -256,6 +270,10 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             ga4[v] = plane0 + (unsigned)(ok ? kZeroSlots + s0 : 2 * lane) * 4u;
             gb4[v] = ga4[v] + (unsigned)ws[v] * 4u;
             ws16[v] = ws[v] * 16;
+            if (kAbsentReads && v >= nv) {                                       // the absent view's one "tap" (its adds are zeros: ds is forced to 0)
+                a0[v] = kAbsentSlot * 16; ws16[v] = 16;
+                w00[v] = 1.f; w01[v] = 0.f; w10[v] = 0.f; w11[v] = 0.f;
+            }
         }
         // ---- chunks of this wave (64 consecutive window slots of one view): DMA source + flush destination
         unsigned g_off[MC];                                              // bit 31: the lane's slot is NOT a window pixel inside the image
@@ -342,8 +360,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         const unsigned aux_base = (unsigned)(size_t)(lds_void_t *)sh->aux;
         const unsigned ch4 = 4u * (lane & 3);                                    // this lane's channel in the flush
         const unsigned long long gk_bits = (unsigned long long)(size_t)gk;
-        const int4v dgk = {uniform((int)(unsigned)gk_bits), uniform((int)((unsigned)(gk_bits >> 32) & 0xffffu)), (int)((unsigned)VT * nq * HW * 16u), 0x00020000};
-        const __amdgpu_buffer_rsrc_t rgk = __builtin_amdgcn_make_buffer_rsrc(gk, 0, (int)((unsigned)VT * nq * HW * 16u), 0x00020000);   // this sample's accumulator
+        const int4v dgk = {uniform((int)(unsigned)gk_bits), uniform((int)((unsigned)(gk_bits >> 32) & 0xffffu)), (int)((unsigned)nv * nq * HW * 16u), 0x00020000};
+        const __amdgpu_buffer_rsrc_t rgk = __builtin_amdgcn_make_buffer_rsrc(gk, 0, (int)((unsigned)nv * nq * HW * 16u), 0x00020000);   // this sample's accumulator
         float ds[4][VT], s[4][VT];
         auto resample = [&](int q) {                                             // samples of quad q from its window buffer
             const int boff = (q & (NBUF - 1)) * buf_bytes;
@@ -368,7 +386,11 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         };
         // ds of channel i of quad q from its samples and gn[i]; the block-wide max |ds| is published for the quad's scale
         auto jacobian_to = [&](int aset, int i, float (&dsi)[VT]) __attribute__((always_inline)) {
-            aggregate_grad<METHOD, VT>(s[i], gn[i], dsi);
+            aggregate_grad<METHOD, VT>(s[i], METHOD == AGG_MEAN ? gn[i] * mean_fix : gn[i], dsi);
+            if (nv < VT) {                                                       // wave-uniform
+#pragma unroll
+                for (int v = 0; v < VT; ++v) dsi[v] = v < nv ? dsi[v] : 0.f;     // a select, not a product: 0 * fma(g, -FLT_MAX, c) can be NaN
+            }
             // max |ds| on the BITS (sign cleared): non-negative floats order as ints, and Inf / NaN (>= 0x7f800000) sort above
             // every finite value instead of being dropped as fmaxf drops a NaN -- a non-finite gradient must stay visible
             int big = 0;
@@ -634,7 +656,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     } else {
         // ---- windows do not fit: scatter straight to the accumulator (its own function: keeps its registers -- 16 tap
         // offsets on top of the weights -- out of the fast path's allocation, which otherwise spills in the quad loop)
-        if (inside) bwd_brick_slow<METHOD, VT, TO>(fk, gobase, gk, sh->proj, c0, c1, c2, vox, N, nq, H, W);
+        if (inside) bwd_brick_slow<METHOD, VT, TO>(fk, gobase, gk, sh->proj, c0, c1, c2, vox, N, nq, H, W, nv);
     }
 }
 
@@ -676,7 +698,7 @@ constexpr int kNTb8 = 512;                            // 8 views: 4 x 4 x 32 bri
 // 32-B runs: still hidden, 18.1 -> 15.1 ms like fp32), 4 x BY x 32 otherwise
 int bwd_brick_z(const Problem &p)
 {
-    const int by = (p.V == 8 || (kExpB & 128)) ? 4 : 8, nt = p.V == 8 ? kNTb8 : kNTb;
+    const int by = (p.V > 4 || (kExpB & 128)) ? 4 : 8, nt = p.V > 4 ? kNTb8 : kNTb;
     if (p.X % 8 == 0 && p.Y % by == 0 && p.Z % 16 == 0) return 16;
     const int by32 = nt / 128;
     if (p.X % kBX == 0 && p.Y % by32 == 0 && p.Z % kBZ == 0) return kBZ;
@@ -702,7 +724,7 @@ hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj,
     if (e != hipSuccess) return e;
     const int grid = ((bps + 7) / 8) * 8 * p.B;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, grad_out, proj, coords, gradK, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps,
-                       lds_bytes, total, make_gate(p, true));
+                       lds_bytes, total, p.V, make_gate(p, true));
     return hipGetLastError();
 }
 
@@ -710,7 +732,7 @@ template <int METHOD, typename TO>
 hipError_t launch_bm(const float4 *featK, const TO *grad_out, const float *proj, const Coords &coords, float *gradK, const Problem &p,
                      hipStream_t s)
 {
-    switch (p.V) {
+    switch (brick_view_slots(p.V)) {                                       // 3 / 5 / 6 / 7 views: the next larger kernel, missing views absent
     case 2:
         if (bwd_brick_z(p) == 16) return launch_bv<METHOD, 2, kNTb, TO, 16>(featK, grad_out, proj, coords, gradK, p, s);
         return launch_bv<METHOD, 2, kNTb, TO>(featK, grad_out, proj, coords, gradK, p, s);
@@ -770,7 +792,7 @@ hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Probl
 bool brick_bwd_supported(const Problem &p)
 {
     if (p.feat_f16 != p.out_f16) return false;                            // fp32 or fp16 storage throughout (or fp32 features with a bf16 volume); other mixes -> gather
-    if (p.V != 2 && p.V != 4 && p.V != 8) return false;
+    if (p.V < 2 || p.V > 8) return false;
     if (p.C % 4) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
     if ((long long)p.V * (p.C / 4) * p.H * p.W >= (1ll << 27)) return false;   // one sample's accumulator: 32-bit byte offsets (buffer atomics)
@@ -781,7 +803,7 @@ bool brick_bwd_supported(const Problem &p)
 
 GateGeom brick_bwd_gate_geom(const Problem &p)
 {
-    const int nt = p.V == 8 ? kNTb8 : kNTb;
+    const int nt = p.V > 4 ? kNTb8 : kNTb;
     GateGeom g;
     g.bz = bwd_brick_z(p);
     g.bx = bwd_brick_x(g.bz); g.by = nt / (g.bz * g.bx); g.column_major = 1; g.view_group = 0; g.parity_rows = 0;

@@ -112,7 +112,7 @@ size_t brick_workspace_bytes(const Problem &p)
 
 // ------------------------------------------------------------------------------------------------- brick geometry
 int fwd_lds_slots() { return (160 * 1024 - 1024) / 16; }
-static int fwd_threads(int V) { return V == 8 ? 512 : 1024; }          // 8 views: 256 VGPRs per lane
+static int fwd_threads(int V) { return V > 4 ? 512 : 1024; }           // 8 view slots: 256 VGPRs per lane
 // 8 x 8 x 32 bricks (two voxels per lane) when x allows; 8 views keep 4 x 4 x 32: their eight windows of a doubled brick (mean
 // ~4 300 slots, max ~6 000 at the configs[3] geometry) overflow the 2-deep ring (4 928) for most bricks
 // (volumes need not divide into bricks: lanes outside the volume idle.  Two voxels per lane whenever the volume is wider than one brick)
@@ -121,11 +121,11 @@ int brick_fwd_nvox(const Problem &p) { return (p.V <= 4 && p.X > kBX) ? 2 : 1; }
 #ifndef MVHMR_NO_GROUPS
 #define MVHMR_NO_GROUPS 0
 #endif
-bool brick_fwd_grouped(const Problem &p) { return !MVHMR_NO_GROUPS && p.V == 8; }
+bool brick_fwd_grouped(const Problem &p) { return !MVHMR_NO_GROUPS && p.V > 4; }     // 5 ... 8 views (the missing ones absent)
 
 bool brick_fwd_supported(const Problem &p)
 {
-    if (p.V != 2 && p.V != 4 && p.V != 8) return false;
+    if (p.V < 2 || p.V > 8) return false;                                 // 3 / 5 / 6 / 7 views: the next larger kernel, missing views absent
     if (p.C % 4) return false;
     // r04: any X, Y, Z -- bricks that stick out of the volume idle their outside lanes.  16-bit volumes store z pairs: Z even.
     if ((p.out_f16 || p.out_bf16) && (p.Z & 1)) return false;

@@ -26,11 +26,11 @@ def _dev(d, key, gpu, dtype=torch.float32):
 
 
 def _brick_ok(f, c):
-    """shapes the brick forward takes (r04): 2 / 4 / 8 views, C % 4 == 0, ANY volume (bricks that stick out idle their outside lanes);
-    16-bit volumes store z pairs and need an even Z"""
+    """shapes the brick forward takes (r04): 2 ... 8 views (3 / 5 / 6 / 7 run the next larger kernel with the missing views absent),
+    C % 4 == 0, ANY volume (bricks that stick out idle their outside lanes); 16-bit volumes store z pairs and need an even Z"""
     Z = c.shape[3]
     V = f.shape[1]
-    return V in (2, 4, 8) and f.shape[2] % 4 == 0 and (f.dtype == torch.float32 or Z % 2 == 0)
+    return 2 <= V <= 8 and f.shape[2] % 4 == 0 and (f.dtype == torch.float32 or Z % 2 == 0)
 
 
 def _bound(ref):
@@ -147,6 +147,12 @@ def test_forward_and_backward_vs_oracle(shape, mode, gpu):
     dict(B=2, V=8, C=16, H=32, W=32, vol=(16, 16, 32)),       # 8 views, 16 bricks per sample
     dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views, group windows of ~4 000 slots: still the 2-deep ring
     dict(B=1, V=8, C=8, H=200, W=200, vol=(4, 8, 32)),        # 8 views, huge maps: the group windows overflow -> out-of-line global path
+    dict(B=2, V=3, C=16, H=24, W=24, vol=(8, 8, 32)),         # 3 views on the 4-view kernel: the fourth view absent
+    dict(B=1, V=5, C=8, H=24, W=24, vol=(8, 8, 32)),          # 5 views on the 8-view kernel (second group: one real view)
+    dict(B=2, V=6, C=16, H=32, W=32, vol=(9, 7, 40)),         # 6 views, ragged volume
+    dict(B=1, V=7, C=8, H=24, W=24, vol=(4, 8, 32)),          # 7 views
+    dict(B=1, V=3, C=8, H=320, W=320, vol=(4, 8, 32)),        # 3 views, windows overflow: out-of-line path with an absent view
+    dict(B=1, V=6, C=8, H=200, W=200, vol=(4, 8, 32)),        # 6 views, group windows overflow
     dict(B=1, V=8, C=8, H=200, W=200, vol=(4, 4, 32)),        # ... and the same for the 512-thread form
 ])
 @pytest.mark.parametrize("mode", MODES)
@@ -215,6 +221,12 @@ def test_brick_softmax_over_the_whole_float_range(views, gpu):
     dict(B=1, V=4, C=8, H=32, W=32, vol=(12, 20, 40)),        # ragged in all three axes, several bricks per axis
     dict(B=1, V=8, C=8, H=24, W=24, vol=(6, 10, 33)),         # 8 views, ragged (8 x 4 x 16 bricks)
     dict(B=1, V=2, C=8, H=24, W=24, vol=(4, 8, 33)),          # ragged in z only: the 4 x 8 x 32 bricks cover it with fewer idle lanes
+    dict(B=2, V=3, C=16, H=24, W=24, vol=(8, 8, 32)),         # 3 views on the 4-view kernel: the fourth view absent (ds forced to zero)
+    dict(B=1, V=5, C=8, H=24, W=24, vol=(8, 8, 32)),          # 5 views on the 8-view kernel
+    dict(B=2, V=6, C=16, H=32, W=32, vol=(9, 7, 40)),         # 6 views, ragged volume
+    dict(B=1, V=7, C=8, H=24, W=24, vol=(4, 8, 32)),          # 7 views
+    dict(B=1, V=3, C=8, H=320, W=320, vol=(4, 8, 32)),        # 3 views, windows overflow: out-of-line path with an absent view
+    dict(B=1, V=6, C=8, H=48, W=48, vol=(8, 8, 32)),          # 6 views, overflow
 ])
 @pytest.mark.parametrize("mode", MODES)
 def test_brick_backward_vs_oracle(shape, mode, gpu):
