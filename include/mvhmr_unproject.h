@@ -81,14 +81,14 @@ typedef enum mvhmr_variant_t {
     MVHMR_VARIANT_AUTO = 0,
     MVHMR_VARIANT_GATHER = 1, /* channel-per-lane gather from L2, any shape */
     MVHMR_VARIANT_BRICK = 2   /* voxel bricks with LDS-staged feature windows (forward) and LDS-accumulated
-                                 gradient windows (backward): C % 4 == 0, 2 ... 8 views (3 and 5 / 6 / 7 views run the 4- and the 8-view
+                                 gradient windows (backward): C % 4 == 0, 1 ... 8 views (1, 3 and 5 / 6 / 7 views run the 2-, 4- and 8-view
                                  kernels with the missing views absent), any volume extents (forward bricks of
                                  4 x 8 x 32 voxels, 8 x 8 x 32 for 2 / 4 views when vol_x > 4; backward 8 x 8 x 16 -- 8 x 4 x 16 with
                                  8 views -- or 4 x 8 x 32 / 4 x 4 x 32, whichever covers the volume with fewer idle lanes; the lanes
                                  of a brick that lie past the volume's edge idle; 16-bit volumes need vol_z even in the forward);
                                  the backward needs one storage type throughout;
                                  anything else is MVHMR_ERR_UNSUPPORTED.
-                                 What therefore runs the GATHER family under AUTO: 1 view or more than 8; C % 4 != 0;
+                                 What therefore runs the GATHER family under AUTO: more than 8 views; C % 4 != 0;
                                  channels-last input; forward launches of fewer than 96 bricks' worth of voxels (B * X * Y * Z <
                                  196 608: one round of bricks costs the same however few they are -- the reference's shipped
                                  16^3 volume, cfg/defaults.py:25, up to batch 47 per GPU); and any call whose cameras / voxel

@@ -30,7 +30,7 @@ def _brick_ok(f, c):
     C % 4 == 0, ANY volume (bricks that stick out idle their outside lanes); 16-bit volumes store z pairs and need an even Z"""
     Z = c.shape[3]
     V = f.shape[1]
-    return 2 <= V <= 8 and f.shape[2] % 4 == 0 and (f.dtype == torch.float32 or Z % 2 == 0)
+    return 1 <= V <= 8 and f.shape[2] % 4 == 0 and (f.dtype == torch.float32 or Z % 2 == 0)
 
 
 def _bound(ref):
@@ -148,6 +148,7 @@ def test_forward_and_backward_vs_oracle(shape, mode, gpu):
     dict(B=2, V=8, C=16, H=48, W=48, vol=(8, 8, 32)),         # 8 views, group windows of ~4 000 slots: still the 2-deep ring
     dict(B=1, V=8, C=8, H=200, W=200, vol=(4, 8, 32)),        # 8 views, huge maps: the group windows overflow -> out-of-line global path
     dict(B=2, V=3, C=16, H=24, W=24, vol=(8, 8, 32)),         # 3 views on the 4-view kernel: the fourth view absent
+    dict(B=2, V=1, C=8, H=24, W=24, vol=(8, 8, 32)),          # a single view on the 2-view kernel
     dict(B=1, V=5, C=8, H=24, W=24, vol=(8, 8, 32)),          # 5 views on the 8-view kernel (second group: one real view)
     dict(B=2, V=6, C=16, H=32, W=32, vol=(9, 7, 40)),         # 6 views, ragged volume
     dict(B=1, V=7, C=8, H=24, W=24, vol=(4, 8, 32)),          # 7 views
@@ -222,6 +223,7 @@ def test_brick_softmax_over_the_whole_float_range(views, gpu):
     dict(B=1, V=8, C=8, H=24, W=24, vol=(6, 10, 33)),         # 8 views, ragged (8 x 4 x 16 bricks)
     dict(B=1, V=2, C=8, H=24, W=24, vol=(4, 8, 33)),          # ragged in z only: the 4 x 8 x 32 bricks cover it with fewer idle lanes
     dict(B=2, V=3, C=16, H=24, W=24, vol=(8, 8, 32)),         # 3 views on the 4-view kernel: the fourth view absent (ds forced to zero)
+    dict(B=2, V=1, C=8, H=24, W=24, vol=(8, 8, 32)),          # a single view on the 2-view kernel
     dict(B=1, V=5, C=8, H=24, W=24, vol=(8, 8, 32)),          # 5 views on the 8-view kernel
     dict(B=2, V=6, C=16, H=32, W=32, vol=(9, 7, 40)),         # 6 views, ragged volume
     dict(B=1, V=7, C=8, H=24, W=24, vol=(4, 8, 32)),          # 7 views
