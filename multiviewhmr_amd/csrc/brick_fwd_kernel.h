@@ -70,6 +70,9 @@ __device__ unsigned long long g_exp_fwd_timers[8];
 #define MVHMR_FWD_MAP16 1          // the lane map of 16-bit volumes: 1 = z runs + pair exchange of channel pairs, 0 = round 3's stride-4 transpose
 #endif
 constexpr int kFwdLay = MVHMR_FWD_LAY, kFwdMapF32 = MVHMR_FWD_MAP, kFwdHp = MVHMR_FWD_HP;
+#ifndef MVHMR_FWD_VADDR
+#define MVHMR_FWD_VADDR 1
+#endif
 #ifndef MVHMR_FWD_STAUX
 #define MVHMR_FWD_STAUX 18
 #endif
@@ -469,8 +472,16 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // ---- taps: two register sets of 4 x b128 (LAY 0: nw, ne, sw, se; LAY 1: even row x0 / x0+1, odd row x0 / x0+1), used
         // alternately by consecutive views
         f32x4 T[2][4];
+        // (MVHMR_FWD_VADDR, default 1) the ring offset and the column strides are held in VGPRs for the tap addresses: a v_add_u32 with an
+        // SGPR operand issues at half rate on gfx950 (profiles/r03_microbench.txt), and a job has 32 of them
+        int ws16v[VT];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            if constexpr (MVHMR_FWD_VADDR) asm volatile("v_mov_b32 %0, %1" : "=v"(ws16v[v]) : "s"(uniform(ws16[v])));
+            else ws16v[v] = ws16[v];
+        }
         auto read_view = [&](int roff, int u, int v, int set) __attribute__((always_inline)) {
-            const int base = a0[u][v] + roff, far = base + ws16[v];
+            const int base = a0[u][v] + roff, far = base + ws16v[v];
             if constexpr (kExp & 2) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -482,7 +493,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 T[set][0] = lds_tap(smem, base); T[set][2] = lds_tap(smem, base + 16);
                 T[set][1] = lds_tap(smem, far); T[set][3] = lds_tap(smem, far + 16);
             } else {
-                const int base1 = a1[u][v] + roff, far1 = base1 + ws16[v];
+                const int base1 = a1[u][v] + roff, far1 = base1 + ws16v[v];
                 T[set][0] = lds_tap(smem, base); T[set][2] = lds_tap(smem, base1);
                 T[set][1] = lds_tap(smem, far); T[set][3] = lds_tap(smem, far1);
             }
@@ -530,14 +541,17 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             if (q == 0) EXP_FT(3);                                               // window 0 landed + barrier
 #endif
             if (nb == 2 && q + 1 < nq) dma(r1);
+            int r0v;                                                             // this quad's ring offset for the tap addresses
+            if constexpr (MVHMR_FWD_VADDR) asm volatile("v_mov_b32 %0, %1" : "=v"(r0v) : "s"(r0));
+            else r0v = r0;
 #pragma unroll
             for (int u = 0; u < NVOX; ++u) {
                 // this job's samples go to sq / sp alternately; the previous job's are aggregated in two halves between the folds
                 // (the live samples stay 16 registers: rows of `prev` die as columns of `cur` are born)
                 auto &cur = ((u + PAR) & 1) ? sp : sq;
                 auto &prev = ((u + PAR) & 1) ? sq : sp;
-                read_view(r0, u, 0, 0);
-                if constexpr (VT > 1) read_view(r0, u, 1, 1);
+                read_view(r0v, u, 0, 0);
+                if constexpr (VT > 1) read_view(r0v, u, 1, 1);
                 __builtin_amdgcn_sched_barrier(0);
                 fwd_aggregate2<METHOD, VT>(prev[0], prev[1], res[0], res[1], mean_fix);
                 __builtin_amdgcn_sched_barrier(0);
@@ -555,7 +569,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                         asm volatile("" : "+v"(cur[i][v]));                       // fold HERE: keeps the tap registers short-lived
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (v + 2 < VT) read_view(r0, u, v + 2, v & 1);
+                    if (v + 2 < VT) read_view(r0v, u, v + 2, v & 1);
                     if (u == DMA_U && v == DMA_V && nb == 3 && q + 2 < nq) dma(r2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
