@@ -71,7 +71,7 @@ __device__ unsigned long long g_exp_fwd_timers[8];
 #endif
 constexpr int kFwdLay = MVHMR_FWD_LAY, kFwdMapF32 = MVHMR_FWD_MAP, kFwdHp = MVHMR_FWD_HP;
 #ifndef MVHMR_FWD_VADDR
-#define MVHMR_FWD_VADDR 1
+#define MVHMR_FWD_VADDR 0          // 1: tap addresses from VGPR operands (full-rate adds); measured, no gain (ablations section L)
 #endif
 #ifndef MVHMR_FWD_STAUX
 #define MVHMR_FWD_STAUX 18
@@ -472,12 +472,14 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // ---- taps: two register sets of 4 x b128 (LAY 0: nw, ne, sw, se; LAY 1: even row x0 / x0+1, odd row x0 / x0+1), used
         // alternately by consecutive views
         f32x4 T[2][4];
-        // (MVHMR_FWD_VADDR, default 1) the ring offset and the column strides are held in VGPRs for the tap addresses: a v_add_u32 with an
-        // SGPR operand issues at half rate on gfx950 (profiles/r03_microbench.txt), and a job has 32 of them
+        // (MVHMR_FWD_VADDR = 1, softmax kernels only: the others have no registers to spare) the ring offset and the column strides
+        // held in VGPRs for the tap addresses: a v_add_u32 with an SGPR operand issues at half rate on gfx950
+        // (profiles/r03_microbench.txt), and a job has 32 of them.  Priced 25 ns per wave and job less; measured: nothing.
+        constexpr bool kVaddr = MVHMR_FWD_VADDR && METHOD == AGG_SOFTMAX;
         int ws16v[VT];
 #pragma unroll
         for (int v = 0; v < VT; ++v) {
-            if constexpr (MVHMR_FWD_VADDR) asm volatile("v_mov_b32 %0, %1" : "=v"(ws16v[v]) : "s"(uniform(ws16[v])));
+            if constexpr (kVaddr) asm volatile("v_mov_b32 %0, %1" : "=v"(ws16v[v]) : "s"(uniform(ws16[v])));
             else ws16v[v] = ws16[v];
         }
         auto read_view = [&](int roff, int u, int v, int set) __attribute__((always_inline)) {
@@ -542,7 +544,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
 #endif
             if (nb == 2 && q + 1 < nq) dma(r1);
             int r0v;                                                             // this quad's ring offset for the tap addresses
-            if constexpr (MVHMR_FWD_VADDR) asm volatile("v_mov_b32 %0, %1" : "=v"(r0v) : "s"(r0));
+            if constexpr (kVaddr) asm volatile("v_mov_b32 %0, %1" : "=v"(r0v) : "s"(r0));
             else r0v = r0;
 #pragma unroll
             for (int u = 0; u < NVOX; ++u) {

@@ -36,6 +36,9 @@ namespace mvhmr {
 //                         MVHMR_BWD_FLUSH_AT channels); costs window capacity (2 368 instead of 3 264 slots)
 //   MVHMR_BWD_FLIP=1      waves 4-7 and 12-15 (two of the four on every SIMD) run each channel as Jacobian -> adds, the others adds -> Jacobian
 //   MVHMR_BWD_PLANE_PAD=16  planes 16 banks apart (kZeroSlots + cap is a multiple of 64: the flush's 4 planes x 16 slots meet in 16 banks)
+#ifndef MVHMR_BWD_ASYNC_G
+#define MVHMR_BWD_ASYNC_G 0           // 1: grad_out loads of the quad loop as inline asm (see load_g_async): measured, no gain
+#endif
 #ifndef MVHMR_BWD_PSETS
 #define MVHMR_BWD_PSETS 1
 #endif
@@ -317,13 +320,47 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<TO *>(gobase) + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gn[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, (int)voxb, (int)(i * chan_bytes), 0));
-            } else {                                                             // fp16 storage: 64-B runs per channel
+            } else {                                                             // 16-bit storage: 64-B runs per channel
+                // plain global loads from the (clamped, always valid) voxel: buffer_load_ushort runs this kernel at 14.9 ms against 12.9.
+                // gn holds the 16 raw bits; the conversion happens where the Jacobian uses them (grad_of) -- a conversion or select here
+                // pins the wait for the load to this spot (13.6 ms)
                 const TO *gp = gobase + (long long)(q * 4) * N + vox;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) gn[i] = inside ? to_f32<TO>(gp[(long long)i * N]) : 0.f;
+                for (int i = 0; i < 4; ++i) gn[i] = __builtin_bit_cast(float, (unsigned)__builtin_bit_cast(unsigned short, gp[(long long)i * N]));
             }
         };
         auto load_g = [&](int q) __attribute__((always_inline)) { load_g_to(q, gn); };
+        // The same loads for the quad loop, as inline asm: OUTSIDE the compiler's wait-count bookkeeping.  The compiler cannot see the
+        // hand-counted wait that ends an iteration (nor the LDS-DMA requests and flush atomics, which are asm too), so for loads it knows
+        // of it guards the first use of every gn[i] in the NEXT iteration with s_waitcnt vmcnt(3 - i) -- counted without the window
+        // requests issued in between, i.e. a wait for those requests in the middle of the add phase.  Built and measured
+        // (MVHMR_BWD_ASYNC_G=1): no difference (fp32 13.06 vs 13.03 ms, fp16 12.87 vs 12.86), so the builtin loads stay.  graw is
+        // written by the load and read only by take_g() behind the hand-counted wait; such a build must not spill VGPRs.
+        float graw[4];
+        auto load_g_async = [&](int q) __attribute__((always_inline)) {
+            if constexpr (sizeof(TO) == 4) {
+                const unsigned long long bits = (unsigned long long)(size_t)(gobase + (long long)(q * 4) * N);
+                const int4v desc = {uniform((int)(unsigned)bits), uniform((int)((unsigned)(bits >> 32) & 0xffffu)), (int)(4u * chan_bytes), 0x00020000};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(graw[i]) : "v"(voxb), "s"(desc), "s"((int)(i * chan_bytes)) : "memory");
+            } else {
+                const TO *gp = gobase + (long long)(q * 4) * N + vox;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("global_load_ushort %0, %1, off" : "=v"(graw[i]) : "v"(gp + (long long)i * N) : "memory");
+            }
+        };
+        auto take_g = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(gn[i]) : "v"(graw[i]));
+        };
+        auto grad_of = [&](float held) __attribute__((always_inline)) {          // the value load_g_to left in gn[i]
+            if constexpr (sizeof(TO) == 4) return held;
+            // (a lane past the volume's edge keeps the gradient of the edge voxel it is clamped to: its weights are zero, so it adds nothing,
+            // and its ds = g / V-like values can only raise the block's scale estimate by a bounded factor.  Zeroing it here would keep the
+            // `inside` mask live through the quad loop: 14.8 ms instead of 12.9 -- SGPR spills in the loop)
+            else return to_f32<TO>(__builtin_bit_cast(TO, (unsigned short)__builtin_bit_cast(unsigned, held)));
+        };
         dma(0);
         load_g(0);
         // ---- most taps any window pixel receives from this brick (once per brick): sizes the fixed-point headroom
@@ -386,7 +423,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         };
         // ds of channel i of quad q from its samples and gn[i]; the block-wide max |ds| is published for the quad's scale
         auto jacobian_to = [&](int aset, int i, float (&dsi)[VT]) __attribute__((always_inline)) {
-            aggregate_grad<METHOD, VT>(s[i], METHOD == AGG_MEAN ? gn[i] * mean_fix : gn[i], dsi);
+            const float gi = grad_of(gn[i]);
+            aggregate_grad<METHOD, VT>(s[i], METHOD == AGG_MEAN ? gi * mean_fix : gi, dsi);
             if (nv < VT) {                                                       // wave-uniform
 #pragma unroll
                 for (int v = 0; v < VT; ++v) dsi[v] = v < nv ? dsi[v] : 0.f;     // a select, not a product: 0 * fma(g, -FLT_MAX, c) can be NaN
@@ -610,7 +648,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 lds_barrier();                                                   // adds of quad q landed, max of quad q+1 published, set of quad q-1 zero
                 EXP_T(5);
             } else {
-                if (q + 2 < nq) load_g(q + 2);
+                if (q + 2 < nq) { if constexpr (MVHMR_BWD_ASYNC_G) load_g_async(q + 2); else load_g(q + 2); }
                 EXP_T(1);                                                        // scales, DMA request, adds + Jacobian issued
                 if constexpr (kExpB & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
                 lds_barrier();                                                   // adds of quad q landed; max of quad q+1 published
@@ -620,6 +658,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 // window q+2 and grad_out q+2 (requested before this quad's atomics) have landed; the atomics stay in flight
                 EXP_T(3);                                                        // flush issued
                 wait_vmcnt((kExpB & 3) ? 0 : n_dyn);
+                if (MVHMR_BWD_ASYNC_G && q + 2 < nq) take_g();
                 EXP_T(4);                                                        // window q+2 / grad_out q+2 landed
                 if constexpr (kExpB & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
                 lds_barrier();

@@ -2,6 +2,7 @@
 vmcnt, check_loops.py rejects scratch inside the tap-reading loops of k_fwd_brick_groups and the accumulation loop of k_bwd_brick,
 and refuses to pass vacuously."""
 import os
+import pytest
 import subprocess
 import sys
 
@@ -98,3 +99,14 @@ def test_plane_backward_has_no_global_atomics_in_its_isa(tmp_path):
     # fp32 / fp16 gradient storage x (4-byte cells with the two-walk 64-bit form inside | 8-byte cells | 8-byte cells, 4 private images); 16 LDS adds per voxel
     assert planes == 6 and adds >= 16 * planes
     assert jacobians >= 4 * 3 * 3                                                  # 4 methods x 3 view counts x 3 grad_out storage types
+
+
+def test_the_library_is_not_older_than_its_sources():
+    """a failed `make` leaves the previous libmvhmr_unproject.so in place and every test would then run against old kernels (it
+    happened in round 4: a resource check failed one unit, the link step never ran).  `make -q` asks whether anything is out of date."""
+    import shutil, subprocess
+    lib = os.path.join(ROOT, "multiviewhmr_amd", "lib", "libmvhmr_unproject.so")
+    if not os.path.exists(lib) or shutil.which("make") is None or not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no built library / no toolchain here")
+    rc = subprocess.call(["make", "-q", "-C", os.path.join(ROOT, "multiviewhmr_amd", "csrc")], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert rc == 0, "multiviewhmr_amd/lib/libmvhmr_unproject.so is older than its sources or objects: run `make -C multiviewhmr_amd/csrc` and read its exit status"
