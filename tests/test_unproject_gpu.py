@@ -960,11 +960,12 @@ def test_conv1x1_wgrad_matches_einsum(gpu):
     record_err("1x1 conv weight gradient (no bias) vs float64 einsum", float((gw2.double() - ref_w).abs().max()), 4e-7 * K ** 0.5 * 8 + 1e-5)
 
 
+@pytest.mark.parametrize("rig", ((2, 4, 32), (6, 3, 32), (1, 6, 64)))     # (B, V, S): the last two run the brick kernels with absent views
 @pytest.mark.parametrize("training", (False, True))
-def test_volume_generator_fused_path_equals_the_unfused_one(training, gpu, monkeypatch):
+def test_volume_generator_fused_path_equals_the_unfused_one(training, rig, gpu, monkeypatch):
     """VolumeGenerator with the fused conv (default where the brick kernels run) against the same module with fused_conv off:
     volume, and in training the gradients of the input features, the conv weight and its bias"""
-    B, V, C, H, S, IMG = 2, 4, 128, 32, 32, 128
+    (B, V, S), C, H, IMG = rig, 128, 32, 128
     rng = np.random.default_rng(61)
     cams = [[None] * B for _ in range(V)]
     for v in range(V):
