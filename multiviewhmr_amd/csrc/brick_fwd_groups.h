@@ -19,7 +19,7 @@ constexpr int kGroupChunks = 4;                       // DMA chunks a wave may o
 // one voxel sampled straight from global memory: taps rebuilt from the projection (clamped taps, zero weights outside)
 template <int METHOD, int VT, typename TO>
 __device__ __attribute__((noinline)) void fwd_groups_slow(const float4 *fk, TO *obase, const float (*proj)[12], const Coords &coords, int b,
-                                                          long long N, unsigned vox, int nq, int H, int W, int nv)
+                                                          long long N, unsigned vox, int nq, int nqv, int H, int W, int nv)
 {
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
     const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
@@ -32,7 +32,7 @@ __device__ __attribute__((noinline)) void fwd_groups_slow(const float4 *fk, TO *
     for (int v = 0; v < VT; ++v) {
         const Taps t = make_taps(proj[v], c0, c1, c2, H, W);
         w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
-        const int base = ((v < nv ? v : 0) * nq) * HW;                          // an absent view reads view 0's pixels (and discards them)
+        const int base = ((v < nv ? v : 0) * nqv) * HW;                         // an absent view reads view 0's pixels (and discards them)
         o00[v] = base + t.x0 * H + t.y0; o01[v] = base + t.x1 * H + t.y0; o10[v] = base + t.x0 * H + t.y1; o11[v] = base + t.x1 * H + t.y1;
     }
     for (int q = 0; q < nq; ++q) {
@@ -63,7 +63,7 @@ __device__ __attribute__((noinline)) void fwd_groups_slow(const float4 *fk, TO *
 template <int METHOD, int VT, typename TO>
 __global__ void __launch_bounds__(1024)
 k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords, TO *__restrict__ out, int C,
-                   int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample, int lds_slots, int total_blocks, int nv, Gate gate)
+                   int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample, int lds_slots, int total_blocks, int nv, int ksplit, Gate gate)
 {
     // nv <= VT real views (5 ... 7 views run this kernel): the others are absent, as in k_fwd_brick
     if (gated_off(gate)) return;
@@ -79,13 +79,14 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
     const int tw = (nbx + tiles_x - 1) / tiles_x, th = (nby + tiles_y - 1) / tiles_y;
     const int share = tw * th * nbz;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int grid0 = (int)gridDim.x / ksplit, part = (int)blockIdx.x / grid0, bid = (int)blockIdx.x - part * grid0;   // channel split: k_fwd_brick
+    const int xcd = bid & 7, j = bid >> 3;
     const int b = j / share, r = j % share;
     const int kz = r % nbz, cy = (r / nbz) % th, cx = r / (nbz * th);
     const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
     if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
     const long long N = (long long)X * Y * Z;
-    const int HW = H * W, nq = C >> 2;
+    const int HW = H * W, nqv = C >> 2, nq = nqv / ksplit, q0 = part * nq;
 
     if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
     if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
@@ -159,8 +160,8 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     const int cap = fwd_cap2(lds_slots);
     const int buf_bytes = kZeroBytes + cap * 16;
     const bool fits = used <= cap && max_chunks <= MC * NW && max_stride + 2 <= kZeroSlots;
-    TO *const obase = out + (long long)b * C * N;
-    const float4 *const fk = featK + (long long)b * nv * nq * HW;
+    TO *const obase = out + (long long)b * C * N + (long long)(q0 * 4) * N;
+    const float4 *const fk = featK + (long long)b * nv * nqv * HW + (long long)q0 * HW;
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
     const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
 
@@ -219,7 +220,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
                     int gx = ox + px, gy = oy + py;
                     gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);
                     gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-                    g_off[g][rr] = (unsigned)(((g * VG + u) * nq) * HW + gx * H + gy) * 16u;
+                    g_off[g][rr] = (unsigned)(((g * VG + u) * nqv) * HW + gx * H + gy) * 16u;
                     l_dst[g][rr] = kZeroBytes + (s0 + (jj << 6)) * 16;
                 }
             }
@@ -324,7 +325,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (its own function: its registers -- 8 views of
         // samples, weights and 64-bit addresses -- stay out of the fast path's allocation)
-        if (inside) fwd_groups_slow<METHOD, VT, TO>(fk, obase, sh->proj, coords, b, N, vox, nq, H, W, nv);
+        if (inside) fwd_groups_slow<METHOD, VT, TO>(fk, obase, sh->proj, coords, b, N, vox, nq, nqv, H, W, nv);
     }
 }
 
@@ -341,7 +342,9 @@ hipError_t launch_fwd_groups_instance(const float4 *featK, const float *proj, co
     if (e != hipSuccess) return e;
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
     const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, p.V, make_gate(p, true));
+    const int ks = brick_fwd_ksplit(total, p.C / 4);
+    hipLaunchKernelGGL(kern, dim3(grid * ks), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, p.V,
+                       ks, make_gate(p, true));
     return hipGetLastError();
 }
 

@@ -186,8 +186,9 @@ template <int METHOD, int VT, int NT, typename TO, int NVOX>
 __global__ void __launch_bounds__(NT)
 k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords,
             TO *__restrict__ out, int C, int H, int W, int X, int Y, int Z, int nby, int nbz, int bricks_per_sample,
-            int lds_slots, int total_blocks, int nv, Gate gate)
+            int lds_slots, int total_blocks, int nv, int ksplit, Gate gate)
 {
+    // ksplit > 1 (launches of fewer bricks than CUs: single-sample inference): the channel quads of a brick are divided among ksplit blocks
     // nv <= VT views are real (3 views run the 4-view kernel): the others have no camera, no window and no part in the aggregate --
     // their samples read kAbsentSample from a slot of the zero region (softmax weight exp(-FLT_MAX - m) = 0, never the maximum) or
     // plain zeros (sum; mean, which is rescaled by VT / nv)
@@ -210,13 +211,14 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
     const int tw = (nbx + tiles_x - 1) / tiles_x, th = (nby + tiles_y - 1) / tiles_y;
     const int share = tw * th * nbz;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int grid0 = (int)gridDim.x / ksplit, part = (int)blockIdx.x / grid0, bid = (int)blockIdx.x - part * grid0;
+    const int xcd = bid & 7, j = bid >> 3;
     const int b = j / share, r = j % share;
     const int kz = r % nbz, cy = (r / nbz) % th, cx = r / (nbz * th);
     const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
     if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
     const long long N = (long long)X * Y * Z;
-    const int HW = H * W, nq = C >> 2;
+    const int HW = H * W, nqv = C >> 2, nq = nqv / ksplit, q0 = part * nq;       // nqv: quads per view (stride); nq: this block's, from q0
 
     if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
     if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
@@ -319,8 +321,8 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     const int cap = nb == 3 ? cap3 : cap2;
     const int buf_bytes = kZeroBytes + cap * 16;
     const bool fits = used <= cap && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots;
-    TO *const obase = out + (long long)b * C * N;
-    const float4 *const fk = featK + (long long)b * nv * nq * HW;
+    TO *const obase = out + (long long)b * C * N + (long long)(q0 * 4) * N;
+    const float4 *const fk = featK + (long long)b * nv * nqv * HW + (long long)q0 * HW;
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;    // absent views sample kAbsentSample (else zeros)
     const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
 
@@ -387,7 +389,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 int gx = ox + px, gy = oy + py;                                  // pad rows / columns past the window / outside the
                 gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);                     // image: clamp -- those slots only meet zero weights
                 gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-                g_off[rr] = (unsigned)((v * nq) * HW + gx * H + gy) * 16u;
+                g_off[rr] = (unsigned)((v * nqv) * HW + gx * H + gy) * 16u;
                 if constexpr (kExp & 4096) g_off[rr] &= 0x1FFF0u;
                 l_dst[rr] = uniform(kZeroBytes + (s0 + (jj << 6)) * 16) + (int)(unsigned)(size_t)(lds_void_t *)smem;
                 ++n_c;
@@ -615,7 +617,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             for (int v = 0; v < VT; ++v) {
                 const int x0 = tx[u][v] < 0 ? 0 : tx[u][v], y0 = ty[u][v] < 0 ? 0 : ty[u][v];
                 const int x1 = tx[u][v] + 1 > W - 1 ? W - 1 : tx[u][v] + 1, y1 = ty[u][v] + 1 > H - 1 ? H - 1 : ty[u][v] + 1;
-                const int base = ((v < nv ? v : 0) * nq) * HW;                  // an absent view reads view 0's pixels (and discards them)
+                const int base = ((v < nv ? v : 0) * nqv) * HW;                 // an absent view reads view 0's pixels (and discards them)
                 o00[v] = base + x0 * H + y0; o01[v] = base + x1 * H + y0; o10[v] = base + x0 * H + y1; o11[v] = base + x1 * H + y1;
             }
             for (int q = 0; q < nq; ++q) {
@@ -647,6 +649,21 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     }
 }
 
+// Few bricks per CU (single-sample inference: 64^3 = 128 bricks on 256 CUs; batch 3: a second round that is half empty): every brick's
+// channel quads are divided among 2 or 4 blocks when that shortens the launch.  Cost model per round of 256 blocks: ~20 us of prologue
+// (tap records, windows, first DMA) + ~3 us per quad (north star: 0.21 ms per round of 64 quads); measured batch 1: 0.181 -> 0.128 ms.
+inline int brick_fwd_ksplit(int bricks, int quads)
+{
+    int best = 1;
+    double best_t = 1e30;
+    for (int ks = 1; ks <= 4; ks *= 2) {
+        if (quads % ks || (ks > 1 && quads / ks < 8)) break;
+        const double t = (double)((bricks * ks + 255) / 256) * (20.0 + 3.0 * quads / ks);
+        if (t < best_t * 0.97) { best_t = t; best = ks; }                         // a split has to pay at least 3 %
+    }
+    return best;
+}
+
 // ---- launch of one instantiation (shared by the per-method translation units)
 int fwd_lds_slots();                                  // 16-B LDS slots of the ring (one block per CU owns all 160 KiB)
 
@@ -662,8 +679,9 @@ hipError_t launch_fwd_instance(const float4 *featK, const float *proj, const Coo
     if (e != hipSuccess) return e;
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
     const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;   // tile work items x 8 XCDs x samples
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, p.V,
-                       make_gate(p, true));
+    const int ks = brick_fwd_ksplit(total, p.C / 4);
+    hipLaunchKernelGGL(kern, dim3(grid * ks), dim3(NT), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, slots, total, p.V,
+                       ks, make_gate(p, true));
     return hipGetLastError();
 }
 

@@ -149,6 +149,10 @@ def test_forward_and_backward_vs_oracle(shape, mode, gpu):
     dict(B=1, V=8, C=8, H=200, W=200, vol=(4, 8, 32)),        # 8 views, huge maps: the group windows overflow -> out-of-line global path
     dict(B=2, V=3, C=16, H=24, W=24, vol=(8, 8, 32)),         # 3 views on the 4-view kernel: the fourth view absent
     dict(B=2, V=1, C=8, H=24, W=24, vol=(8, 8, 32)),          # a single view on the 2-view kernel
+    dict(B=1, V=4, C=64, H=48, W=48, vol=(32, 32, 32)),       # 16 bricks, 16 quads: the channel quads divided among 2 blocks per brick
+    dict(B=1, V=4, C=128, H=24, W=24, vol=(16, 16, 32)),      # 4 bricks, 32 quads: 4 blocks per brick
+    dict(B=1, V=8, C=64, H=32, W=32, vol=(16, 16, 32)),       # 8 views (view groups), 16 bricks, 2 blocks per brick
+    dict(B=1, V=3, C=64, H=32, W=32, vol=(9, 16, 40)),        # split + absent view + ragged volume
     dict(B=1, V=5, C=8, H=24, W=24, vol=(8, 8, 32)),          # 5 views on the 8-view kernel (second group: one real view)
     dict(B=2, V=6, C=16, H=32, W=32, vol=(9, 7, 40)),         # 6 views, ragged volume
     dict(B=1, V=7, C=8, H=24, W=24, vol=(4, 8, 32)),          # 7 views
