@@ -21,6 +21,10 @@ def run(seed=1, cases=60, big=False, dtype="f32", verbose=True):
         V = int(rng.choice([2, 4, 4, 8] if seed < 100 else [1, 3, 5, 6, 7])); C = int(rng.choice([4, 8, 12, 20]))
         H, W = int(rng.integers(12, 60)), int(rng.integers(12, 60))
         X, Y, Z = int(rng.choice([4, 8, 12, 16])), int(rng.choice([8, 16])), int(rng.choice([16, 32, 64]))
+        if seed >= 200:                                                           # r04: any view count 1 ... 8, any volume extents, enough quads for the channel split
+            V = int(rng.integers(1, 9)); C = int(rng.choice([8, 32, 36, 64]))
+            X, Y, Z = int(rng.integers(3, 21)), int(rng.integers(3, 21)), int(rng.integers(5, 71))
+            if a.dtype != "f32": Z += Z & 1                                         # 16-bit volumes store z pairs
         if a.big:
             H, W = int(rng.integers(60, 220)), int(rng.integers(60, 220))
             X, Y, Z = int(rng.choice([8, 16])), int(rng.choice([8, 12, 16])), int(rng.choice([32, 64]))

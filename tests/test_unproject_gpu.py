@@ -1530,10 +1530,11 @@ def test_northstar_full_tensor_cuboid_route_rotated(gpu):
     record_err("north star cuboid route, sample 9, 2 channels vs oracle", err, TOL)
 
 
-@pytest.mark.parametrize("seed,big", [(1, False), (22, False), (5, True)])
+@pytest.mark.parametrize("seed,big", [(1, False), (22, False), (5, True), (101, False), (201, False)])
 def test_fuzz_parity_fixed_seeds(seed, big, gpu):
-    """three fixed seeds of scripts/fuzz_parity.py (random rigs incl. rolled ones, cuboids, volumes, maps, every variant, forward +
-    backward against the C oracle); seed 22 is the one that found the fine-grid plane route in round 3"""
+    """fixed seeds of scripts/fuzz_parity.py (random rigs incl. rolled ones, cuboids, volumes, maps, every variant, forward +
+    backward against the C oracle); seed 22 is the one that found the fine-grid plane route in round 3; seeds >= 100 draw the view
+    counts without kernels of their own (1, 3, 5, 6, 7), seeds >= 200 any view count, any volume extents and 8 ... 16 channel quads"""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
