@@ -477,7 +477,14 @@ class VolumeGenerator(nn.Module):
             thetas = np.random.uniform(0.0, 2 * np.pi, size=batch_size)
             rots = volumetric.get_rotation_matrices(axis, thetas).astype(np.float32)
         else:
-            rots = np.broadcast_to(volumetric.get_rotation_matrix(axis, 0.0).astype(np.float32), (batch_size, 3, 3))
+            # theta = 0 for every sample: the same matrices call after call -- kept on the device, so that an eval forward with packed
+            # cameras and tensor keypoints copies nothing from the host (and can be captured into a HIP graph: scripts/graph_volgen.py)
+            key = (batch_size, proj_matricies_org.device)
+            cache = self.__dict__.setdefault("_eval_rots", {})
+            if key not in cache:
+                r0 = np.broadcast_to(volumetric.get_rotation_matrix(axis, 0.0).astype(np.float32), (batch_size, 3, 3))
+                cache[key] = torch.from_numpy(np.ascontiguousarray(r0)).to(proj_matricies_org.device)
+            rots = None
         if self.use_triangulation:
             # one batched DLT on the device, no per-sample .cpu(); stays a device tensor
             n_views = proj_matricies_org.shape[1]
@@ -489,6 +496,8 @@ class VolumeGenerator(nn.Module):
                 centers = kp[:, 6, :3].to(torch.float32)
             else:
                 centers = torch.from_numpy(np.stack([np.asarray(kp[b][6, :3], dtype=np.float32) for b in range(batch_size)]))
+        if rots is None:
+            return cache[key], centers
         return torch.from_numpy(np.ascontiguousarray(rots)), centers
 
     def coord_volumes(self, rots, centers, device):

@@ -666,6 +666,33 @@ def test_forward_is_graph_capturable(gpu):
     record_err("HIP-graph replay fwd", _err(out.cpu().numpy(), ref), TOL)
 
 
+def test_volume_generator_eval_forward_is_graph_capturable(gpu):
+    """the whole eval forward of VolumeGenerator -- packed cameras and tensor keypoints: projections, pose, fused conv, gate and
+    un-projection all on the device, nothing copied from the host -- captured into a HIP graph; the replay on new feature values
+    equals the eager call bit for bit (scripts/graph_volgen.py times both)"""
+    B, V, C, H, S, IMG = 2, 4, 128, 32, 32, 128
+    cams = _rig(B, V, 5000.0, IMG, seed=4)
+    batch = dict(images=np.zeros((B, V, IMG, IMG, 3), np.uint8), cameras=cams, cameras_packed=aggregation.pack_cameras(cams, gpu),
+                 keypoints_3d=torch.zeros(B, 17, 3, device=gpu))
+    proj_org = torch.from_numpy(np.stack([[cams[v][b].projection for v in range(V)] for b in range(B)]).astype(np.float32)).to(gpu)
+    torch.manual_seed(2)
+    gen = aggregation.VolumeGenerator(volume_size=S, input_channels=C, output_channels=C, device=gpu).eval()
+    x = torch.randn(B, V, C, H, H, device=gpu)
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            gen(x, proj_org, batch)                      # warm-up outside the capture (kernel attributes, the cached eval rotations)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = gen(x, proj_org, batch)
+        x.copy_(torch.randn_like(x))                     # new values, same buffers
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, gen(x, proj_org, batch))
+
+
 # ------------------------------------------------------------------------------------ round 2: shard-size forward AND backward
 def _sparse_backward_check(f, p, c, proj, coords, out, b, chans, name, half=False):
     """gradient of sum(out * g) for a g that is non-zero on one sample and a few channels: the oracle only has to run on
