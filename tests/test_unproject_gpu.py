@@ -666,6 +666,30 @@ def test_forward_is_graph_capturable(gpu):
     record_err("HIP-graph replay fwd", _err(out.cpu().numpy(), ref), TOL)
 
 
+def test_channels_last_features_take_the_bricks_where_they_pay(gpu):
+    """a channels-last-strided feature tensor feeds the gather kernels without a layout pass -- except where the library's AUTO choice
+    for the problem is the brick kernels (from 96 bricks' worth of voxels on): the binding then makes it planar first.  Same values
+    and gradients as the planar tensor, bit for bit, and the gradient keeps working through autograd whatever its strides."""
+    feats, proj, coords = _ring_problem(B=1, V=4, C=16, H=48, W=48, vol=(64, 64, 48), seed=13)      # 196 608 voxels
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    planar = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    cl = torch.from_numpy(feats).to(gpu).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3).requires_grad_(True)
+    assert aggregation._is_channels_last5(cl) and not cl.is_contiguous()
+    assert aggregation._feature_layout(cl, c, _capi.AGG["softmax"], torch.float32, _capi.VARIANT["auto"])[1] == _capi.LAYOUT_BVCHW
+    assert aggregation._feature_layout(cl, c, _capi.AGG["softmax"], torch.float32, _capi.VARIANT["gather"])[1] == _capi.LAYOUT_BVHWC
+    go = torch.randn(1, 16, 64, 64, 48, device=gpu, generator=torch.Generator(device=gpu).manual_seed(3))
+    outs, grads = [], []
+    for f in (planar, cl):
+        out = aggregation.unprojection(f, p, c)
+        out.backward(go)
+        outs.append(out.detach()); grads.append(f.grad.clone())
+    assert torch.equal(outs[0], outs[1])
+    record_err("channels-last input through the bricks: gradient vs the planar input's", float((grads[0] - grads[1]).abs().max()),
+               2e-5 * float(grads[0].abs().max()))                       # float atomics in the flush: last-bit differences run to run
+    small = torch.from_numpy(feats[:, :, :, :24, :24].copy()).to(gpu).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
+    assert aggregation._feature_layout(small, (8, 8, 32), _capi.AGG["softmax"], torch.float32, _capi.VARIANT["auto"])[1] == _capi.LAYOUT_BVHWC
+
+
 def test_volume_generator_eval_forward_is_graph_capturable(gpu):
     """the whole eval forward of VolumeGenerator -- packed cameras and tensor keypoints: projections, pose, fused conv, gate and
     un-projection all on the device, nothing copied from the host -- captured into a HIP graph; the replay on new feature values
