@@ -86,7 +86,7 @@ typedef enum mvhmr_variant_t {
                                  4 x 8 x 32 voxels, 8 x 8 x 32 for 2 / 4 views when vol_x > 4; backward 8 x 8 x 16 -- 8 x 4 x 16 with
                                  8 views -- or 4 x 8 x 32 / 4 x 4 x 32, whichever covers the volume with fewer idle lanes; the lanes
                                  of a brick that lie past the volume's edge idle; 16-bit volumes need vol_z even in the forward);
-                                 the backward needs one storage type throughout;
+                                 every storage pairing check_desc admits (fp32 / fp16 features with an fp32, fp16 or -- fp32 features -- bf16 volume);
                                  anything else is MVHMR_ERR_UNSUPPORTED.
                                  What therefore runs the GATHER family under AUTO: more than 8 views; C % 4 != 0;
                                  channels-last input; forward launches of fewer than 96 bricks' worth of voxels (B * X * Y * Z <

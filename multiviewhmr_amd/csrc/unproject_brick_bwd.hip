@@ -830,7 +830,7 @@ hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Probl
 
 bool brick_bwd_supported(const Problem &p)
 {
-    if (p.feat_f16 != p.out_f16) return false;                            // fp32 or fp16 storage throughout (or fp32 features with a bf16 volume); other mixes -> gather
+    if ((p.out_f16 && !p.feat_f16) || (p.out_bf16 && p.feat_f16)) return false;   // grad_out and the feature gradient each in their own storage type; these two pairings do not exist (capi: check_desc)
     if (p.V < 1 || p.V > 8) return false;
     if (p.C % 4) return false;
     if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;

@@ -418,6 +418,15 @@ def test_fp16_storage_mode(views, gpu):
     out32 = aggregation.unprojection(f16, p, c, out_dtype=torch.float32)
     assert out32.dtype == torch.float32
     record_err("fp16 features, fp32 volume V%d" % views, _err(out32.cpu().numpy(), ref), TOL)
+    # ... and its backward on every kernel family (r04: the brick backward takes this pairing too -- fp32 grad_out, fp16 feature gradient)
+    go32 = torch.randn(out32.shape, device=gpu, generator=torch.Generator(device=gpu).manual_seed(17))
+    g32ref = cport.backward(go32.cpu().numpy(), f16.float().cpu().numpy(), proj, coords, "softmax")
+    for variant in ("auto", "brick", "gather"):
+        fm = f16.clone().requires_grad_(True)
+        aggregation.unprojection(fm, p, c, out_dtype=torch.float32, variant=variant).backward(go32)
+        assert fm.grad.dtype == torch.float16
+        record_err("fp16 features, fp32 volume bwd %s V%d" % (variant, views), _err(fm.grad.float().cpu().numpy(), g32ref),
+                   TOL + np.abs(g32ref).max() * 2.0 ** -10)
     f16g = f16.clone().requires_grad_(True)
     go = torch.randn_like(out16)
     aggregation.unprojection(f16g, p, c).backward(go)
