@@ -179,6 +179,8 @@ int mvhmr_unproject_backward_cuboid(const mvhmr_unproject_desc *desc, const void
 /*
  * Layout pass on its own: features (B,V,C,Hf,Wf) -> dst in `dst_layout` (MVHMR_LAYOUT_BVHWC with the channel
  * count rounded up to a multiple of 4 and zero padded, or MVHMR_LAYOUT_QUAD), desc->feat_dtype.
+ * desc->feat_layout names the SOURCE: MVHMR_LAYOUT_BVCHW (also assumed for MVHMR_LAYOUT_QUAD descriptors, as before), or
+ * MVHMR_LAYOUT_BVHWC -- channels-last features to MVHMR_LAYOUT_QUAD only (how a channels-last caller reaches the brick kernels).
  * mvhmr_unproject_forward runs the pass its kernel needs into its workspace when desc->feat_layout is
  * MVHMR_LAYOUT_BVCHW; callers that keep the converted copy (or time the two kernels separately) call this and
  * then pass desc->feat_layout = dst_layout.  mvhmr_preferred_layout says which layout the kernel that

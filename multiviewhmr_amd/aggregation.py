@@ -45,16 +45,27 @@ def _is_channels_last5(features):
 
 
 def _feature_layout(features, vol, method, out_dtype, variant):
-    """-> (features as the library will read them, layout code).  A channels-last-strided tensor (physically (B,V,Hf,Wf,C)) feeds the
-    gather kernels without a layout pass; where the library's AUTO choice for the same problem in planar layout is the brick kernels
-    (3-4x the forward, 8x the backward at the north-star size) it is made planar first -- one transposing copy, still far ahead."""
+    """-> (what the library reads, its layout code, a tensor whose shape / dtype describe the features).
+    A channels-last-strided tensor (physically (B,V,Hf,Wf,C)) feeds the gather kernels without a layout pass; where the library's AUTO
+    choice for the same problem in planar layout is the brick kernels (3-4x the forward, 8x the backward at the north-star size) it is
+    converted for them first: fp32 by the library's own channels-last -> quad-planar pass (the copy the brick kernels stage from; the
+    backward then returns a planar gradient), fp16 through a planar copy."""
     if not _is_channels_last5(features):
-        return features.contiguous(), _capi.LAYOUT_BVCHW
+        features = features.contiguous()
+        return features, _capi.LAYOUT_BVCHW, features
     if variant == _capi.VARIANT["auto"]:
+        L = _capi.lib()
         desc = _make_desc(features, vol, method, out_dtype, _capi.LAYOUT_BVCHW, variant)
-        if _capi.lib().mvhmr_unproject_selected_variant(ctypes.byref(desc)) == _capi.VARIANT["brick"]:
-            return features.contiguous(), _capi.LAYOUT_BVCHW
-    return features, _capi.LAYOUT_BVHWC
+        if L.mvhmr_unproject_selected_variant(ctypes.byref(desc)) == _capi.VARIANT["brick"]:
+            if features.dtype != torch.float32:
+                features = features.contiguous()
+                return features, _capi.LAYOUT_BVCHW, features
+            src = _make_desc(features, vol, method, out_dtype, _capi.LAYOUT_BVHWC, variant)
+            with torch.cuda.device(features.device):
+                quad = torch.empty(L.mvhmr_feature_layout_bytes(ctypes.byref(src), _capi.LAYOUT_QUAD), dtype=torch.uint8, device=features.device)
+                _capi.check(L.mvhmr_convert_features(ctypes.byref(src), _ptr(features), _capi.LAYOUT_QUAD, _ptr(quad), _stream(features.device)))
+            return quad, _capi.LAYOUT_QUAD, features
+    return features, _capi.LAYOUT_BVHWC, features
 
 
 def _dtype_code(dt):
@@ -91,9 +102,9 @@ _DTYPES = {_capi.F32: torch.float32, _capi.F16: torch.float16, _capi.BF16: torch
 
 def _op_forward(features, proj, coords, method, out_dtype, variant):
     L = _capi.lib()
-    features, layout = _feature_layout(features, coords, method, _DTYPES[out_dtype], variant)
-    desc = _make_desc(features, coords, method, _DTYPES[out_dtype], layout, variant)
-    B, C = features.shape[0], features.shape[2]
+    features, layout, like = _feature_layout(features, coords, method, _DTYPES[out_dtype], variant)
+    desc = _make_desc(like, coords, method, _DTYPES[out_dtype], layout, variant)
+    B, C = like.shape[0], like.shape[2]
     with torch.cuda.device(features.device):
         out = torch.empty((B, C) + tuple(coords.shape[1:4]), dtype=_DTYPES[out_dtype], device=features.device)
         ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), features.device)
@@ -105,11 +116,12 @@ def _op_forward(features, proj, coords, method, out_dtype, variant):
 def _op_backward(grad_out, features, proj, coords, method, out_dtype, variant):
     """gradient w.r.t. features only: proj_matricies and coord_volumes come from numpy / arange in the caller and never require grad"""
     L = _capi.lib()
-    features, layout = _feature_layout(features, coords, method, _DTYPES[out_dtype], variant)
-    desc = _make_desc(features, coords, method, _DTYPES[out_dtype], layout, variant)
+    features, layout, like = _feature_layout(features, coords, method, _DTYPES[out_dtype], variant)
+    desc = _make_desc(like, coords, method, _DTYPES[out_dtype], layout, variant)
     grad_out = grad_out.contiguous()
     with torch.cuda.device(features.device):
-        grad_features = torch.empty_like(features)               # keeps the (possibly channels-last) strides
+        # same strides as what the library read -- except quad-planar features, whose gradient comes back planar
+        grad_features = torch.empty(like.shape, dtype=like.dtype, device=like.device) if layout == _capi.LAYOUT_QUAD else torch.empty_like(features)
         ws, wsp = _workspace(L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc)), features.device)
         _capi.check(L.mvhmr_unproject_backward(ctypes.byref(desc), _ptr(grad_out), _ptr(features), _ptr(proj), _ptr(coords),
                                                _ptr(grad_features), wsp, 0 if ws is None else ws.numel(), _stream(features.device)))
@@ -215,9 +227,9 @@ def _d3(values):
 
 def _opc_forward(features, proj, rot, center, position, sides, vol, method, out_dtype, variant):
     L = _capi.lib()
-    features, layout = _feature_layout(features, vol, method, _DTYPES[out_dtype], variant)
-    desc = _make_desc(features, vol, method, _DTYPES[out_dtype], layout, variant)
-    B, C = features.shape[0], features.shape[2]
+    features, layout, like = _feature_layout(features, vol, method, _DTYPES[out_dtype], variant)
+    desc = _make_desc(like, vol, method, _DTYPES[out_dtype], layout, variant)
+    B, C = like.shape[0], like.shape[2]
     with torch.cuda.device(features.device):
         out = torch.empty((B, C) + tuple(vol), dtype=_DTYPES[out_dtype], device=features.device)
         ws, wsp = _workspace(L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(desc)), features.device)
@@ -228,11 +240,11 @@ def _opc_forward(features, proj, rot, center, position, sides, vol, method, out_
 
 def _opc_backward(grad_out, features, proj, rot, center, position, sides, vol, method, out_dtype, variant):
     L = _capi.lib()
-    features, layout = _feature_layout(features, vol, method, _DTYPES[out_dtype], variant)
-    desc = _make_desc(features, vol, method, _DTYPES[out_dtype], layout, variant)
+    features, layout, like = _feature_layout(features, vol, method, _DTYPES[out_dtype], variant)
+    desc = _make_desc(like, vol, method, _DTYPES[out_dtype], layout, variant)
     grad_out = grad_out.contiguous()
     with torch.cuda.device(features.device):
-        grad_features = torch.empty_like(features)
+        grad_features = torch.empty(like.shape, dtype=like.dtype, device=like.device) if layout == _capi.LAYOUT_QUAD else torch.empty_like(features)
         ws, wsp = _workspace(L.mvhmr_unproject_backward_workspace_bytes(ctypes.byref(desc)), features.device)
         _capi.check(L.mvhmr_unproject_backward_cuboid(ctypes.byref(desc), _ptr(grad_out), _ptr(features), _ptr(proj), _ptr(rot), _ptr(center),
                                                       _d3(position), _d3(sides), _ptr(grad_features), wsp, 0 if ws is None else ws.numel(),

@@ -533,11 +533,17 @@ int mvhmr_convert_features(const mvhmr_unproject_desc *desc, const void *feature
     Problem p;
     if (!desc) return fail(MVHMR_ERR_INVALID_ARGUMENT, "descriptor is null");
     mvhmr_unproject_desc d = *desc;
+    const bool from_channels_last = desc->feat_layout == MVHMR_LAYOUT_BVHWC;      // r04: a channels-last source (to MVHMR_LAYOUT_QUAD only)
     d.feat_layout = MVHMR_LAYOUT_BVCHW;
     int rc = check_desc(&d, &p);
     if (rc != MVHMR_OK) return rc;
     if (!features || !dst) return fail(MVHMR_ERR_INVALID_ARGUMENT, "features / dst must be non-null");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (from_channels_last) {
+        if (dst_layout != MVHMR_LAYOUT_QUAD) return fail(MVHMR_ERR_UNSUPPORTED, "channels-last features convert to MVHMR_LAYOUT_QUAD only");
+        p.gate_count = nullptr;
+        return launched(launch_channels_last_to_quad_planar_t(features, dst, p, s), "layout pass");
+    }
     if (dst_layout == MVHMR_LAYOUT_BVHWC) return launched(launch_to_channels_last(features, dst, p, s), "layout pass");
     if (dst_layout == MVHMR_LAYOUT_QUAD) return launched(launch_to_quad_planar_t(features, dst, p, s), "layout pass");
     return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown destination layout %d", dst_layout);

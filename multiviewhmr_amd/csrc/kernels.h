@@ -55,6 +55,8 @@ bool brick_fwd_supported(const Problem &p);
 bool brick_bwd_supported(const Problem &p);
 size_t brick_workspace_bytes(const Problem &p);
 hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s, bool brick_side = true);
+// the same copy from channels-last features (BV, H, W, C)
+hipError_t launch_channels_last_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s);
 hipError_t launch_fwd_brick(const void *featK, const float *proj, const Coords &coords, void *out, const Problem &p,
                             hipStream_t s);
 

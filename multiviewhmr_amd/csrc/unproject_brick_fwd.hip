@@ -104,6 +104,43 @@ hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p,
     return hipGetLastError();
 }
 
+// Channels-last features (BV, H, W, C) -> the same column-major quad-planar copy.  One block = 16 image rows of one column, all
+// quads 64 at a time: read as 1-KiB runs along the channels (64 quads x 16 B), turned through LDS, written as 256-B runs along y.
+template <typename TF>
+__global__ void __launch_bounds__(256)
+k_channels_last_to_quad_t(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int H, int W, Gate gate)
+{
+    if (gated_off(gate)) return;
+    __shared__ float4 tile[64][17];                                              // [quad][row], padded: the column-wise reads hit distinct banks
+    const long long bv = blockIdx.z;
+    const int w = blockIdx.y, h0 = blockIdx.x << 4, nq = C >> 2;
+    for (int qc = 0; qc < nq; qc += 64) {
+        for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+            const int hh = idx >> 6, ql = idx & 63;
+            if (h0 + hh < H && qc + ql < nq) {
+                const TF *s = src + ((bv * H + h0 + hh) * W + w) * (long long)C + 4 * (qc + ql);
+                tile[ql][hh] = make_float4(to_f32<TF>(s[0]), to_f32<TF>(s[1]), to_f32<TF>(s[2]), to_f32<TF>(s[3]));
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < 64 * 16; idx += 256) {
+            const int ql = idx >> 4, hh = idx & 15;
+            if (h0 + hh < H && qc + ql < nq) dst[((bv * nq + qc + ql) * W + w) * (long long)H + h0 + hh] = tile[ql][hh];
+        }
+        __syncthreads();
+    }
+}
+
+hipError_t launch_channels_last_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s)
+{
+    if (p.C % 4 || p.W > 65535 || p.B * p.V > 65535) return hipErrorNotSupported;
+    const dim3 grid((p.H + 15) / 16, p.W, p.B * p.V);
+    const Gate gate = make_gate(p, true);
+    if (p.feat_f16) hipLaunchKernelGGL(k_channels_last_to_quad_t<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, gate);
+    else hipLaunchKernelGGL(k_channels_last_to_quad_t<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, gate);
+    return hipGetLastError();
+}
+
 size_t brick_workspace_bytes(const Problem &p)
 {
     const size_t n = (size_t)p.B * p.V * p.C * p.H * p.W * sizeof(float);

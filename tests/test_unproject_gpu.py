@@ -684,8 +684,20 @@ def test_channels_last_features_take_the_bricks_where_they_pay(gpu):
     planar = torch.from_numpy(feats).to(gpu).requires_grad_(True)
     cl = torch.from_numpy(feats).to(gpu).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3).requires_grad_(True)
     assert aggregation._is_channels_last5(cl) and not cl.is_contiguous()
-    assert aggregation._feature_layout(cl, c, _capi.AGG["softmax"], torch.float32, _capi.VARIANT["auto"])[1] == _capi.LAYOUT_BVCHW
+    # fp32: the library's own channels-last -> quad-planar pass (the copy the bricks stage from); fp16: a planar copy
+    assert aggregation._feature_layout(cl, c, _capi.AGG["softmax"], torch.float32, _capi.VARIANT["auto"])[1] == _capi.LAYOUT_QUAD
+    assert aggregation._feature_layout(cl.detach().half(), c, _capi.AGG["softmax"], torch.float16, _capi.VARIANT["auto"])[1] == _capi.LAYOUT_BVCHW
     assert aggregation._feature_layout(cl, c, _capi.AGG["softmax"], torch.float32, _capi.VARIANT["gather"])[1] == _capi.LAYOUT_BVHWC
+    # the pass itself against the planar -> quad-planar pass
+    L = _capi.lib()
+    d_pl = aggregation._make_desc(planar, c, _capi.AGG["softmax"], torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["auto"])
+    d_cl = aggregation._make_desc(cl, c, _capi.AGG["softmax"], torch.float32, _capi.LAYOUT_BVHWC, _capi.VARIANT["auto"])
+    nb = L.mvhmr_feature_layout_bytes(ctypes.byref(d_pl), _capi.LAYOUT_QUAD)
+    qa, qb = torch.zeros(nb, dtype=torch.uint8, device=gpu), torch.ones(nb, dtype=torch.uint8, device=gpu)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _capi.check(L.mvhmr_convert_features(ctypes.byref(d_pl), ctypes.c_void_p(planar.data_ptr()), _capi.LAYOUT_QUAD, ctypes.c_void_p(qa.data_ptr()), stream))
+    _capi.check(L.mvhmr_convert_features(ctypes.byref(d_cl), ctypes.c_void_p(cl.data_ptr()), _capi.LAYOUT_QUAD, ctypes.c_void_p(qb.data_ptr()), stream))
+    assert torch.equal(qa, qb)
     go = torch.randn(1, 16, 64, 64, 48, device=gpu, generator=torch.Generator(device=gpu).manual_seed(3))
     outs, grads = [], []
     for f in (planar, cl):
@@ -697,6 +709,14 @@ def test_channels_last_features_take_the_bricks_where_they_pay(gpu):
                2e-5 * float(grads[0].abs().max()))                       # float atomics in the flush: last-bit differences run to run
     small = torch.from_numpy(feats[:, :, :, :24, :24].copy()).to(gpu).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)
     assert aggregation._feature_layout(small, (8, 8, 32), _capi.AGG["softmax"], torch.float32, _capi.VARIANT["auto"])[1] == _capi.LAYOUT_BVHWC
+    # fp16 channels-last features through the planar copy: forward + backward against the planar fp16 tensor
+    ph = torch.from_numpy(feats).to(gpu).half().requires_grad_(True)
+    ch = torch.from_numpy(feats).to(gpu).half().permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3).requires_grad_(True)
+    oh = [aggregation.unprojection(t, p, c) for t in (ph, ch)]
+    assert torch.equal(oh[0], oh[1])
+    for o in oh: o.backward(go.half())
+    record_err("fp16 channels-last input through the bricks: gradient vs the planar input's", float((ph.grad.float() - ch.grad.float()).abs().max()),
+               2.0 ** -9 * float(ph.grad.float().abs().max()))
 
 
 def test_volume_generator_eval_forward_is_graph_capturable(gpu):
