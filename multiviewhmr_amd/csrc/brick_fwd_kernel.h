@@ -70,6 +70,9 @@ __device__ unsigned long long g_exp_fwd_timers[8];
 #define MVHMR_FWD_MAP16 1          // the lane map of 16-bit volumes: 1 = z runs + pair exchange of channel pairs, 0 = round 3's stride-4 transpose
 #endif
 constexpr int kFwdLay = MVHMR_FWD_LAY, kFwdMapF32 = MVHMR_FWD_MAP, kFwdHp = MVHMR_FWD_HP;
+#ifndef MVHMR_FWD_PRIO
+#define MVHMR_FWD_PRIO 0           // experiment: s_setprio 3 around the stores (bit 0) / from the stores to behind the LDS-DMA site (bit 1)
+#endif
 #ifndef MVHMR_FWD_VADDR
 #define MVHMR_FWD_VADDR 0          // 1: tap addresses from VGPR operands (full-rate adds); measured, no gain (ablations section L)
 #endif
@@ -563,8 +566,10 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 for (int v = 0; v < VT; ++v) {
                     if (v == (VT + 1) / 2) {
                         fwd_aggregate2<METHOD, VT>(prev[2], prev[3], res[2], res[3], mean_fix);
+                        if constexpr (MVHMR_FWD_PRIO & 1) __builtin_amdgcn_s_setprio(3);  // experiment: memory instructions ahead of the other waves' arithmetic
                         if (u > 0) store_quad(rs_cur, u - 1, res);
                         else if (q > 0) store_quad(rs_prev, NVOX - 1, res);
+                        if constexpr (MVHMR_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -574,7 +579,11 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (v + 2 < VT) read_view(r0v, u, v + 2, v & 1);
-                    if (u == DMA_U && v == DMA_V && nb == 3 && q + 2 < nq) dma(r2);
+                    if (u == DMA_U && v == DMA_V && nb == 3 && q + 2 < nq) {
+                        if constexpr (MVHMR_FWD_PRIO & 2) __builtin_amdgcn_s_setprio(3);
+                        dma(r2);
+                    }
+                    if constexpr (MVHMR_FWD_PRIO & 2) { if (v == DMA_V) __builtin_amdgcn_s_setprio(0); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
