@@ -425,9 +425,10 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         auto jacobian_to = [&](int aset, int i, float (&dsi)[VT]) __attribute__((always_inline)) {
             const float gi = grad_of(gn[i]);
             aggregate_grad<METHOD, VT>(s[i], METHOD == AGG_MEAN ? gi * mean_fix : gi, dsi);
-            if (nv < VT) {                                                       // wave-uniform
+            if (nv < VT) {                                                       // wave-uniform, as is every test below
 #pragma unroll
-                for (int v = 0; v < VT; ++v) dsi[v] = v < nv ? dsi[v] : 0.f;     // a select, not a product: 0 * fma(g, -FLT_MAX, c) can be NaN
+                for (int v = 1; v < VT; ++v)                                     // a move, not a product: 0 * fma(g, -FLT_MAX, c) can be NaN.  (As
+                    if (v >= nv) asm volatile("v_mov_b32 %0, 0" : "=v"(dsi[v])); // selects the compiler keeps VT lane masks in SGPR pairs across the loop)
             }
             // max |ds| on the BITS (sign cleared): non-negative floats order as ints, and Inf / NaN (>= 0x7f800000) sort above
             // every finite value instead of being dropped as fmaxf drops a NaN -- a non-finite gradient must stay visible
