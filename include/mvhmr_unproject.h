@@ -30,9 +30,9 @@
 extern "C" {
 #endif
 
-#define MVHMR_ABI_VERSION 3   /* 2: MVHMR_LAYOUT_QUAD became column-major (B,V,C/4,Wf,Hf,4).  3: QUAD + AUTO is geometry-gated and needs its
+#define MVHMR_ABI_VERSION 4   /* 2: MVHMR_LAYOUT_QUAD became column-major (B,V,C/4,Wf,Hf,4).  3: QUAD + AUTO is geometry-gated and needs its
                                  workspace; explicit GATHER with QUAD input is served; MVHMR_BF16 out_dtype; mvhmr_unproject_backward_supported,
-                                 mvhmr_triangulate_dlt (ABI history) */
+                                 mvhmr_triangulate_dlt.  4: MVHMR_LAYOUT_QUAD_LOG2E (ABI history) */
 
 typedef enum mvhmr_status_t {
     MVHMR_OK = 0,
@@ -65,12 +65,17 @@ typedef enum mvhmr_layout_t {
     MVHMR_LAYOUT_BVCHW = 0, /* (B,V,C,Hf,Wf) -- the reference's contract (aggregation.py:22-23, :191) */
     MVHMR_LAYOUT_BVHWC = 1, /* (B,V,Hf,Wf,C) -- channels-last, what the gather variant reads; passing it
                                skips the layout pass (e.g. a channels_last 1x1 conv upstream) */
-    MVHMR_LAYOUT_QUAD = 2   /* (B,V,C/4,Wf,Hf,4) fp32 whatever feat_dtype -- column-major "quad-planar": a pixel's 4 channels
+    MVHMR_LAYOUT_QUAD = 2,  /* (B,V,C/4,Wf,Hf,4) fp32 whatever feat_dtype -- column-major "quad-planar": a pixel's 4 channels
                                are 16 contiguous bytes and a pixel COLUMN is one contiguous run, which is what the brick
                                forward stages into LDS (tall narrow tap windows); produced by mvhmr_convert_features and by
                                mvhmr_conv1x1_to_quad (C % 4 == 0).  Forward and backward accept it; the backward then writes
                                grad_features PLANAR (B,V,C,Hf,Wf).  With MVHMR_VARIANT_AUTO the geometry gate decides on the
                                device as for planar input (the gather side converts the copy to channels-last first) */
+    MVHMR_LAYOUT_QUAD_LOG2E = 3 /* the same copy with every value multiplied by log2(e), FORWARD ONLY: what the wave-specialised softmax
+                               forward stages (3 / 4 views, fp32 volume, launches of >= 256 bricks): its exponentials are then exp2 of
+                               a plain difference and ln 2 is folded into the final multiply (<= 2e-7 relative to the unscaled
+                               route).  mvhmr_preferred_layout returns it exactly when the forward accepts it; the backward and every
+                               other shape / aggregate answer MVHMR_ERR_UNSUPPORTED.  A forward on planar input makes this copy itself */
 } mvhmr_layout_t;
 
 /* kernel selection; AUTO picks the fastest applicable one.  The others exist for tests and profiling.

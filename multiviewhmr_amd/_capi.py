@@ -8,11 +8,11 @@ import os
 PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG, "lib", "libmvhmr_unproject.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 OK, ERR_INVALID_ARGUMENT, ERR_UNSUPPORTED, ERR_WORKSPACE, ERR_LAUNCH = range(5)
 AGG = {"softmax": 0, "sum": 1, "mean": 2, "max": 3}
 F32, F16, BF16 = 0, 1, 2
-LAYOUT_BVCHW, LAYOUT_BVHWC, LAYOUT_QUAD = 0, 1, 2
+LAYOUT_BVCHW, LAYOUT_BVHWC, LAYOUT_QUAD, LAYOUT_QUAD_LOG2E = 0, 1, 2, 3
 VARIANT = {"auto": 0, "gather": 1, "brick": 2}
 
 EXPORTS = (

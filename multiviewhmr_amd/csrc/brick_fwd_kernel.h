@@ -699,11 +699,24 @@ bool brick_fwd_grouped(const Problem &p);
 template <int METHOD, int VT, typename TO>
 hipError_t launch_fwd_groups_instance(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s);
 
+// 3 / 4 views, fp32 volume, chip-filling launches: the wave-specialised kernel (brick_fwd_ws.h); PRE: the staged copy is multiplied by log2(e)
+bool brick_fwd_ws_shape(const Problem &p);
+template <int METHOD, bool PRE>
+hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const Coords &coords, float *out, const Problem &p, hipStream_t s);
+
 // one aggregation method: views x storage type x voxels per lane
 template <int METHOD>
 hipError_t launch_fwd_method(const void *featK_, const float *proj, const Coords &coords, void *out, const Problem &p, int nvox, hipStream_t s)
 {
     const float4 *featK = static_cast<const float4 *>(featK_);
+    if (brick_fwd_ws_shape(p)) {
+        if constexpr (METHOD == AGG_SOFTMAX) {
+            if (p.feat_log2e) return launch_fwd_ws_instance<METHOD, true>(featK, proj, coords, (float *)out, p, s);
+        }
+        if (p.feat_log2e) return hipErrorNotSupported;
+        return launch_fwd_ws_instance<METHOD, false>(featK, proj, coords, (float *)out, p, s);
+    }
+    if (p.feat_log2e) return hipErrorNotSupported;                               // only the wave-specialised softmax reads a prescaled copy
 #define MVHMR_FWD_CASE(NVIEWS, NTHR, NV)                                                                                                 \
     if (brick_view_slots(p.V) == NVIEWS && nvox == NV)                                                                                                   \
         return p.out_f16    ? launch_fwd_instance<METHOD, NVIEWS, NTHR, __half, NV>(featK, proj, coords, (__half *)out, p, s)            \

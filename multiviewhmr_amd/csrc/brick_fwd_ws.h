@@ -1,0 +1,508 @@
+// Fused un-projection forward, WAVE-SPECIALISED brick kernel (gfx950 / CDNA4 only) -- round 5.
+//
+// Reference semantics: models/aggregation.py:20-87 (projection, depth mask, bilinear grid_sample with zero padding, cross-view
+// aggregate); the arithmetic order of the projection and of the bilinear sample is pinned in device_common.h.
+//
+// Why.  profiles/r05_fwd_ablations.txt: with the arithmetic removed, the LDS-DMA window fills and the volume stores of k_fwd_brick
+// take 2.8-2.9 ms of its 3.3 ms by themselves (stores alone 1.7 = the HBM write rate, window fills alone 1.1, and the two do not
+// overlap: both live off the ~88 requests a CU keeps in flight), the arithmetic alone 2.5 ms -- and the two ADD UP to 3.3 because
+// every wave does both: a wave whose store or LDS-DMA instruction waits for room in the vector-memory FIFOs issues no arithmetic.
+// A timing build in which 4 of the 16 waves issued every memory instruction and the other 12 only computed ran at the memory floor.
+//
+// Mapping.
+//   block    = one 8 x 8 x 32 brick, 768 threads = 4 MEMORY waves + 8 COMPUTE waves (three waves per SIMD, <= 168 VGPRs);
+//   compute  = wave cw owns the brick's row y = cw: lane = (x parity, z), four voxels per lane (x = parity + 2u).  Tap records
+//              (two LDS addresses + four weights per voxel and view) live in registers for all C / 4 channel quads.  A job
+//              (quad, voxel) is 16 ds_read_b128 + 64 FMAs + the aggregate; its four results go to the result buffer R in LDS as
+//              four ds_write_b32.  Compute waves never issue a vector-memory instruction;
+//   memory   = per quad: (A) wait for its LDS-DMA pieces of this quad's windows, barrier A (publishes the windows), read last quad's
+//              results from R (8 x ds_read_b128 per wave), barrier B (R is free again), request the next quad's windows
+//              (global_load_lds_dwordx4, pieces wave, wave + 4, ...), store last quad's results (8 x buffer_store_dwordx4 per wave:
+//              one instruction = 8 rows y x 128 B of one channel plane).  These waves spend their time waiting for FIFO room --
+//              that is their job;
+//   LDS      = two window buffers EXACTLY 64 512 B apart (the quad loop is unrolled by two and the second buffer is addressed
+//              through the 16-bit offset field of ds_read_b128: no per-quad address arithmetic), R = 32 KiB behind them;
+//   windows  = as k_fwd_brick: per view the bounding box of the brick's taps, column-major, rows split by parity.
+// Softmax (PRE = true): the layout pass has multiplied the staged features by log2(e), so e_v = exp2(t_v - t_0) costs one
+// subtraction, and ln 2 is folded into the final multiply; the overflow test is one compare per job (sum of the four denominators
+// below 2^60: then no e_v * t_v can overflow either) with the max form as the wave-uniform fallback.  <= 2e-7 relative to the
+// unscaled form; sum / mean / max read an unscaled copy and stay bit-exact.
+#pragma once
+#include "brick_fwd_groups.h"
+
+namespace mvhmr {
+
+constexpr int kWsThreads = 768, kWsMemWaves = 4, kWsCompWaves = 8, kWsNvox = 4;
+constexpr int kWsBufBytes = 64512;                                   // window buffer: zero region + 3 904 slots; < 65 536: a DS offset
+constexpr int kWsCapSlots = (kWsBufBytes - kZeroBytes) / 16;
+constexpr int kWsResBytes = 4 * 64 * 32 * 4;                         // R[channel][column = x * 8 + y][z] fp32
+constexpr int kWsLdsBytes = 2 * kWsBufBytes + kWsResBytes;           // FwdShared<VT> behind it
+constexpr int kWsChunks = 16;                                        // LDS-DMA pieces per memory wave and quad (64 x 64 slots >= cap)
+static_assert(kWsCapSlots % 64 == 0 && kWsCapSlots <= kWsChunks * kWsMemWaves * 64, "window pool / chunk table");
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+#ifndef MVHMR_WS_EXP
+#define MVHMR_WS_EXP 0                                                            // timing-only (scripts/exp): 1 no LDS-DMA / stores, 2 no arithmetic, 4 no barrier B
+#endif
+constexpr int kWsExp = MVHMR_WS_EXP;
+
+// window geometry of a brick (block-uniform; the same arithmetic in both roles and in k_brick_gate)
+template <int VT>
+struct WsWindows {
+    int wx0[VT], wy0[VT], ws[VT], whp[VT], slot0[VT], nch[VT + 1];
+    bool fits;
+};
+
+template <int VT>
+__device__ __forceinline__ void ws_size_windows(const FwdShared<VT> *sh, WsWindows<VT> &w)
+{
+    int used = 0, max_stride = 0;
+    auto size = [&](bool round8) __attribute__((always_inline)) {
+        w.nch[0] = 0; used = 0; max_stride = 0;
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const int xmin = uniform(sh->bbox[v][0]), ymin = uniform(sh->bbox[v][1]);
+            const int xmax = uniform(sh->bbox[v][2]), ymax = uniform(sh->bbox[v][3]);
+            const int y0w = ymin & ~1;                                           // origin row even: rows split by parity
+            int bw = 0, hp = 0;
+            if (xmax >= xmin) { bw = xmax - xmin + 2; hp = (ymax + 3 - y0w) >> 1; }   // taps reach x0 + 1, y0 + 1
+            if (round8) hp = (hp + 7) & ~7;
+            const int stride = 2 * hp, chunks = (stride * bw + 63) >> 6;
+            w.wx0[v] = xmin; w.wy0[v] = y0w; w.ws[v] = stride; w.whp[v] = hp;
+            max_stride = stride > max_stride ? stride : max_stride;
+            w.slot0[v] = used;
+            used += chunks << 6;
+            w.nch[v + 1] = w.nch[v] + chunks;
+        }
+    };
+    size(true);                                                                  // hp = 0 mod 8: conflict-free tap reads (sim_lds5b.py)
+    if (!(used <= kWsCapSlots && max_stride + 2 <= kZeroSlots)) size(false);
+    w.fits = used <= kWsCapSlots && max_stride + 2 <= kZeroSlots;
+}
+
+// softmax of one channel pair on samples t = log2(e) * s (PRE) or s; weights relative to view 0; da + db comes back for the job's
+// overflow test.  Transcendentals in runs (device_common.h aggregate2).
+template <int V, bool PRE>
+__device__ __forceinline__ void ws_softmax_pair(const float (&sa)[V], const float (&sb)[V], float &ra, float &rb, float &dsum)
+{
+    float ta[V], tb[V];
+#pragma unroll
+    for (int v = 1; v < V; ++v) {
+        ta[v] = PRE ? sa[v] - sa[0] : (sa[v] - sa[0]) * kLog2e;
+        tb[v] = PRE ? sb[v] - sb[0] : (sb[v] - sb[0]) * kLog2e;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 1; v < V; ++v) { ta[v] = __builtin_amdgcn_exp2f(ta[v]); tb[v] = __builtin_amdgcn_exp2f(tb[v]); }
+    __builtin_amdgcn_sched_barrier(0);
+    float da = 1.f, db = 1.f, na = sa[0], nb = sb[0];
+#pragma unroll
+    for (int v = 1; v < V; ++v) {
+        da += ta[v]; na = fmaf(ta[v], sa[v], na);
+        db += tb[v]; nb = fmaf(tb[v], sb[v], nb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    float ia = __builtin_amdgcn_rcpf(da), ib = __builtin_amdgcn_rcpf(db);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PRE) { ia *= kLn2; ib *= kLn2; }
+    ra = na * ia;
+    rb = nb * ib;
+    dsum = da + db;                                                              // both below 2^60 and no NaN: no e_v reached 2^60, so no e_v * t_v overflowed
+}
+
+// the max form (any finite samples): aggregate<AGG_SOFTMAX> on unscaled samples; on prescaled ones the same with exp2(t - m)
+template <int V, bool PRE>
+__device__ __forceinline__ float ws_softmax_safe(const float (&s)[V])
+{
+    if constexpr (!PRE) {
+        return aggregate<AGG_SOFTMAX, V>(s);
+    } else {
+        float m = s[0];
+#pragma unroll
+        for (int v = 1; v < V; ++v) m = vmax(m, s[v]);
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float e = __builtin_amdgcn_exp2f(s[v] - m);
+            den += e;
+            num = fmaf(e, s[v], num);
+        }
+        return num * (__builtin_amdgcn_rcpf(den) * kLn2);
+    }
+}
+
+// one voxel sampled straight from global memory (windows that do not fit LDS); `unscale` = ln 2 for a prescaled copy, else 1
+template <int METHOD, int VT, typename TO>
+__device__ __attribute__((noinline)) void ws_slow_voxel(const float4 *fk, TO *obase, const float (*proj)[12], const Coords &coords, int b,
+                                                        long long N, unsigned vox, int nq, int nqv, int H, int W, int nv, float unscale)
+{
+    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    const int HW = H * W;
+    float c0, c1, c2;
+    voxel_xyz(coords, b, N, vox, c0, c1, c2);
+    float w00[VT], w01[VT], w10[VT], w11[VT];
+    int o00[VT], o01[VT], o10[VT], o11[VT];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        const Taps t = make_taps(proj[v], c0, c1, c2, H, W);
+        w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
+        const int base = ((v < nv ? v : 0) * nqv) * HW;                         // an absent view reads view 0's pixels (and discards them)
+        o00[v] = base + t.x0 * H + t.y0; o01[v] = base + t.x1 * H + t.y0; o10[v] = base + t.x0 * H + t.y1; o11[v] = base + t.x1 * H + t.y1;
+    }
+    for (int q = 0; q < nq; ++q) {
+        const float4 *src = fk + (long long)q * HW;
+        float s[4][VT];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const float4 a = src[o00[v]], bb = src[o01[v]], c = src[o10[v]], d = src[o11[v]];
+            s[0][v] = bilerp(a.x, bb.x, c.x, d.x, w00[v], w01[v], w10[v], w11[v]) * unscale;
+            s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[v], w01[v], w10[v], w11[v]) * unscale;
+            s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]) * unscale;
+            s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]) * unscale;
+            if (v >= nv) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i][v] = kAbsentReads ? kAbsentSample : 0.f;
+            }
+        }
+        TO *oq = obase + (long long)(q * 4) * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r;
+            if constexpr (METHOD == AGG_MEAN) r = __fdiv_rn(aggregate<AGG_SUM, VT>(s[i]), (float)nv);
+            else r = aggregate<METHOD, VT>(s[i]);
+            (oq + i * N)[vox] = from_f32<TO>(r);
+        }
+    }
+}
+
+template <int METHOD, int VT, typename TO, bool PRE>
+__global__ void __launch_bounds__(kWsThreads)
+k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords, TO *__restrict__ out, int C, int H, int W,
+         int X, int Y, int Z, int nby, int nbz, int bricks_per_sample, int total_blocks, int nv, Gate gate)
+{
+    // nv <= VT views are real (3 views run the 4-view kernel): the others have no camera, no window and no part in the aggregate --
+    // their samples read kAbsentSample from a slot of the zero region (softmax, max) or plain zeros (sum, mean)
+    if (gated_off(gate)) return;
+    static_assert(sizeof(TO) == 4, "fp32 volumes (16-bit volumes: k_fwd_brick)");
+    static_assert(!PRE || METHOD == AGG_SOFTMAX, "only the softmax reads a prescaled copy");
+    constexpr int NVOX = kWsNvox, NMW = kWsMemWaves, BX = 8, BY = 8;
+    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    extern __shared__ __align__(16) unsigned char smem[];
+    FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + kWsLdsBytes);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
+    const bool memw = wave < NMW;
+
+    // XCD-aware order as in k_fwd_brick (speed only): blocks i, i + 8, ... share an XCD under round-robin dispatch; all eight XCDs work
+    // on the same sample, each on a compact tile of brick columns (all z)
+    const int nbx = bricks_per_sample / (nby * nbz);
+    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
+    const int tw = (nbx + tiles_x - 1) / tiles_x, th = (nby + tiles_y - 1) / tiles_y;
+    const int share = tw * th * nbz;
+    const int bid = (int)blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int b = j / share, r = j % share;
+    const int kz = r % nbz, cy = (r / nbz) % th, cx = r / (nbz * th);
+    const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
+    if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
+    const long long N = (long long)X * Y * Z;
+    const int HW = H * W, nq = C >> 2;
+    TO *const obase = out + (long long)b * C * N;
+    const float4 *const fk = featK + (long long)b * nv * nq * HW;
+    const unsigned chan_bytes = (unsigned)(N * sizeof(TO));
+    const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
+
+    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
+    if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
+    __syncthreads();
+
+    if (memw) {
+        // ================================================================ memory waves
+        __syncthreads();                                                         // the compute waves' boxes are complete
+        WsWindows<VT> win;
+        ws_size_windows<VT>(sh, win);
+        if (!win.fits) return;                                                   // the compute waves sample from global memory
+        // ---- LDS-DMA pieces of this wave: piece c = wave + 4 rr covers 64 consecutive slots of one view's window (the views are
+        // packed back to back in 64-slot chunks, so piece c lands at slot 64 c of the buffer)
+        unsigned go[kWsChunks];
+        int n_m = 0;
+#pragma unroll
+        for (int rr = 0; rr < kWsChunks; ++rr) {
+            const int c = wave + rr * NMW;
+            go[rr] = 0;
+            if (c < win.nch[VT]) {
+                int v = 0;
+#pragma unroll
+                for (int uu = 1; uu < VT; ++uu) v += c >= win.nch[uu] ? 1 : 0;
+                int sv = win.ws[0], ox = win.wx0[0], oy = win.wy0[0], c0 = win.nch[0], hv = win.whp[0];
+#pragma unroll
+                for (int uu = 1; uu < VT; ++uu) if (v == uu) { sv = win.ws[uu]; ox = win.wx0[uu]; oy = win.wy0[uu]; c0 = win.nch[uu]; hv = win.whp[uu]; }
+                const int slot = ((c - c0) << 6) + lane;
+                const int px = slot / sv;
+                int py = slot - px * sv;
+                py = py >= hv ? 2 * (py - hv) + 1 : 2 * py;                      // slot inside the column -> row (even rows first)
+                int gx = ox + px, gy = oy + py;                                  // pad rows / columns past the window / outside the
+                gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);                     // image: clamp -- those slots only meet zero weights
+                gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
+                go[rr] = (unsigned)((v * nq) * HW + gx * H + gy) * 16u;
+                ++n_m;
+            }
+        }
+        const float4 *src_n = fk;                                                // plane of the next quad to request
+        auto dma = [&](int boff) __attribute__((always_inline)) {
+#pragma unroll
+            for (int rr = 0; rr < kWsChunks; ++rr)
+                if (rr < n_m && !(kWsExp & 1)) glds16_m0(src_n, go[rr], lds_base + (unsigned)(boff + kZeroBytes + (wave + rr * NMW) * 1024));
+            src_n += HW;
+        };
+        // ---- stores: instruction j = wave + 4 k (k < 8) writes channel j >> 3, brick column x = j & 7: lane = (y, z quad) reads
+        // R[j >> 3][(j & 7) * 8 + y][4 z4 ..] (1 KiB contiguous per instruction) and writes 16 B; 8 lanes = one 128-B row
+        const int yl = lane >> 3, z4 = lane & 7;
+        const int vy = ky * BY + yl, vz = kz * kBZ + z4 * 4;
+        const unsigned voff = (vy < Y && vz < Z) ? (unsigned)((((long long)(kx * BX) * Y + vy) * Z + vz) * (long long)sizeof(TO)) : 0xFFFFFFF0u;   // beyond num_records: dropped
+        const unsigned xstep = (unsigned)((long long)Y * Z * sizeof(TO));
+        int n_st = 0;                                                            // store instructions of this wave per quad
+#pragma unroll
+        for (int k = 0; k < 8; ++k) n_st += kx * BX + ((wave + 4 * k) & 7) < X ? 1 : 0;
+        const int r_rd = kWsResBytes == 0 ? 0 : 2 * kWsBufBytes + wave * 1024 + lane * 16;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+        dma(0);                                                                  // quad 0 -> buffer 0
+        for (int q = 0; q <= nq; ++q) {
+            // the pieces of quad q have landed: younger than them are only the n_st stores issued behind them (none before quad 2)
+            if (q < nq) {
+                if (q < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else wait_vmcnt_ladder<0, 8, 8>(n_st);
+            }
+            bare_barrier();                                                      // A(q): windows of quad q published; results of quad q - 1 complete
+            float4 res[8];
+            if (q > 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) res[k] = *reinterpret_cast<const float4 *>(smem + r_rd + k * 4096);
+            }
+            if (q < nq) {
+                if constexpr (!(kWsExp & 4)) lds_barrier();                      // B(q): R has been read, the compute waves may write quad q's results
+                if (q + 1 < nq) dma(((q + 1) & 1) * kWsBufBytes);                // every wave has passed A(q): the other buffer is free
+            }
+            if (q > 0) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)((q - 1) * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int jj = wave + 4 * k, xs = jj & 7, ch = jj >> 3;
+                    if (kx * BX + xs < X && !(kWsExp & 1)) {
+                        const u32x4 d = {__builtin_bit_cast(unsigned, res[k].x), __builtin_bit_cast(unsigned, res[k].y),
+                                         __builtin_bit_cast(unsigned, res[k].z), __builtin_bit_cast(unsigned, res[k].w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)voff, (int)(xs * xstep + ch * chan_bytes), kStAux);
+                    }
+                }
+            }
+        }
+        return;
+    }
+
+    // ==================================================================== compute waves
+    const int cw = wave - NMW;                                                   // brick row y
+    int dcol, zin;
+    fwd_lane_voxel<1>(lane, dcol, zin);                                          // lane = 32 * (x parity) + z (z quads permuted: LDS pass groups are z runs)
+    const int vy_r = ky * BY + cw, vz_r = kz * kBZ + zin;
+    const bool in_yz = vy_r < Y && vz_r < Z;
+    const int vy = vy_r < Y ? vy_r : Y - 1, vz = vz_r < Z ? vz_r : Z - 1;
+    unsigned vox[NVOX];
+    bool inside[NVOX];
+    float w00[NVOX][VT], w01[NVOX][VT], w10[NVOX][VT], w11[NVOX][VT];
+    int tx[NVOX][VT], ty[NVOX][VT];
+    unsigned valid = 0;
+    {
+        int bxmin[VT], bymin[VT], bxmax[VT], bymax[VT];
+        const int big = 1 << 30;
+#pragma unroll
+        for (int v = 0; v < VT; ++v) { bxmin[v] = big; bymin[v] = big; bxmax[v] = -big; bymax[v] = -big; }
+#pragma unroll
+        for (int u = 0; u < NVOX; ++u) {
+            const int vx_r = kx * BX + dcol + 2 * u;
+            inside[u] = in_yz && vx_r < X;
+            const int vx = vx_r < X ? vx_r : X - 1;                              // outside the volume: the clamped edge voxel's centre, no part in the windows
+            vox[u] = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_fwd_supported)
+            float c0, c1, c2;
+            voxel_xyz(coords, b, N, vox[u], c0, c1, c2);
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
+                w00[u][v] = t.w00; w01[u][v] = t.w01; w10[u][v] = t.w10; w11[u][v] = t.w11;
+                tx[u][v] = t.rx0; ty[u][v] = t.ry0;
+                if (t.any && inside[u] && v < nv) {
+                    valid |= 1u << (u * VT + v);
+                    bxmin[v] = t.rx0 < bxmin[v] ? t.rx0 : bxmin[v]; bxmax[v] = t.rx0 > bxmax[v] ? t.rx0 : bxmax[v];
+                    bymin[v] = t.ry0 < bymin[v] ? t.ry0 : bymin[v]; bymax[v] = t.ry0 > bymax[v] ? t.ry0 : bymax[v];
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const int nxmin = wave_max_dpp(-bxmin[v]), nymin = wave_max_dpp(-bymin[v]);
+            const int xmax = wave_max_dpp(bxmax[v]), ymax = wave_max_dpp(bymax[v]);
+            if (lane == 0 && xmax >= -nxmin) {
+                atomicMin(&sh->bbox[v][0], -nxmin); atomicMin(&sh->bbox[v][1], -nymin);
+                atomicMax(&sh->bbox[v][2], xmax); atomicMax(&sh->bbox[v][3], ymax);
+            }
+        }
+    }
+    __syncthreads();
+    WsWindows<VT> win;
+    ws_size_windows<VT>(sh, win);
+
+    if (!win.fits) {
+        // ---- windows do not fit the LDS pool: sample straight from global memory (the memory waves have left)
+#pragma unroll 1
+        for (int u = 0; u < NVOX; ++u)
+            if (inside[u]) ws_slow_voxel<METHOD, VT, TO>(fk, obase, sh->proj, coords, b, N, vox[u], nq, nq, H, W, nv, PRE ? kLn2 : 1.f);
+        return;
+    }
+
+    // zero regions at the head of both window buffers (samples that are identically zero read them); absent views: kAbsentSample
+    for (int i = tid - NMW * 64; i < kZeroSlots * 2; i += kWsCompWaves * 64) {
+        const float z = (kAbsentReads && nv < VT && i % kZeroSlots == kAbsentSlot) ? kAbsentSample : 0.f;
+        *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * kWsBufBytes + (i % kZeroSlots) * 16) = make_float4(z, z, z, z);
+    }
+    // ---- LDS byte offsets (inside a buffer) of the taps in column x0: a0 = the EVEN row of the footprint, a1 = the odd row; column
+    // x0 + 1 is one column stride further.  The weights are kept in that order (even row x0, even row x0 + 1, odd row x0, odd row
+    // x0 + 1): for an odd y0 the sum runs sw, se, nw, ne instead of ATen's nw, ne, sw, se -- <= 1 ulp of the sample.
+    // (both in one register: buffer-relative offsets are below 2^16)
+    unsigned ap[NVOX][VT];
+    int ws16[VT];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        int s16 = win.ws[v] * 16;
+        if (kAbsentReads && v >= nv) s16 = 16;                                   // "one column further": the zero slot next to the absent sample
+        asm volatile("v_mov_b32 %0, %1" : "=v"(ws16[v]) : "s"(s16));           // in a VGPR: v_add_u32 v, v, v issues at the full rate, v, s, v at half
+#pragma unroll
+        for (int u = 0; u < NVOX; ++u) {
+            const bool ok = (valid >> (u * VT + v)) & 1u;
+            const int yr = ty[u][v] - win.wy0[v];
+            const int sc = win.slot0[v] + (tx[u][v] - win.wx0[v]) * win.ws[v];
+            int a0 = ok ? kZeroBytes + (sc + ((yr + 1) >> 1)) * 16 : 0;
+            int a1 = ok ? kZeroBytes + (sc + win.whp[v] + (yr >> 1)) * 16 : 0;
+            if (yr & 1) {
+                const float t0 = w00[u][v], t1 = w01[u][v];
+                w00[u][v] = w10[u][v]; w01[u][v] = w11[u][v]; w10[u][v] = t0; w11[u][v] = t1;
+            }
+            if (kAbsentReads && v >= nv) {                                       // wave-uniform: the absent view's one "tap"
+                a0 = kAbsentSlot * 16; a1 = kAbsentSlot * 16;
+                w00[u][v] = 1.f; w01[u][v] = 0.f; w10[u][v] = 0.f; w11[u][v] = 0.f;
+            }
+            ap[u][v] = (unsigned)a0 | ((unsigned)a1 << 16);
+        }
+    }
+    // R address of this lane's voxel u = 0, channel 0: column (x parity) * 8 + y; voxel u is 2 u columns of 8 x 32 floats further,
+    // channel i 64 columns further: immediate offsets
+    const int rbase = 2 * kWsBufBytes + ((dcol * 8 + cw) * 32 + zin) * 4;
+
+    f32x4 T[2][4];
+    float sq[4][VT], sp[4][VT], res[4];
+    auto read_view = [&](auto boff, int u, int v, int set) __attribute__((always_inline)) {
+        constexpr int BOFF = decltype(boff)::value;
+        unsigned pk = ap[u][v];
+        asm volatile("" : "+v"(pk));                                             // unpacked per use: hoisted out of the quad loop, the 64 addresses would spill
+        const int base = (int)(pk & 0xFFFFu), base1 = (int)(pk >> 16), far = base + ws16[v], far1 = base1 + ws16[v];
+        T[set][0] = lds_tap(smem, base + BOFF); T[set][2] = lds_tap(smem, base1 + BOFF);
+        T[set][1] = lds_tap(smem, far + BOFF); T[set][3] = lds_tap(smem, far1 + BOFF);
+    };
+    // the aggregate of one job in two halves (channels 0 / 1, then 2 / 3 + the job's overflow test)
+    auto agg_half = [&](float (&s)[4][VT], auto half) __attribute__((always_inline)) {
+        constexpr int h = decltype(half)::value;
+        if constexpr (METHOD == AGG_SOFTMAX && VT > 1) {
+            float d;
+            ws_softmax_pair<VT, PRE>(s[2 * h], s[2 * h + 1], res[2 * h], res[2 * h + 1], d);
+            if (__builtin_amdgcn_ballot_w64(!(d < 1.152921504606847e18f)) != 0) {  // wave-uniform: redo the pair in the max form
+                res[2 * h] = ws_softmax_safe<VT, PRE>(s[2 * h]);
+                res[2 * h + 1] = ws_softmax_safe<VT, PRE>(s[2 * h + 1]);
+            }
+        } else if constexpr (METHOD == AGG_MEAN) {
+            res[2 * h] = __fdiv_rn(aggregate<AGG_SUM, VT>(s[2 * h]), (float)nv);
+            res[2 * h + 1] = __fdiv_rn(aggregate<AGG_SUM, VT>(s[2 * h + 1]), (float)nv);
+        } else {
+            res[2 * h] = aggregate<METHOD, VT>(s[2 * h]);
+            res[2 * h + 1] = aggregate<METHOD, VT>(s[2 * h + 1]);
+        }
+    };
+    auto write_results = [&](int u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float *>(smem + rbase + i * 8192 + u * 2048) = res[i];
+    };
+
+    // One quad.  Jobs u = 0 .. 3: request views 0 and 1, first half of the PREVIOUS job's aggregate, fold view 0 / request view 2,
+    // fold view 1 / request view 3, second half of the previous aggregate + its four results to R, fold views 2 and 3.  Barrier B sits in
+    // front of the quad's first write to R.  The last job is aggregated behind the loop, then lgkmcnt(0) + barrier A of the next quad.
+    constexpr int VH = (VT + 1) / 2;
+    auto quad_iter = [&](auto boff) __attribute__((always_inline)) {
+        if constexpr (kWsExp & 2) {
+            if constexpr (!(kWsExp & 4)) bare_barrier();
+            write_results(0);
+            lds_barrier();
+            return;
+        }
+#pragma unroll
+        for (int u = 0; u < NVOX; ++u) {
+            auto &cur = (u & 1) ? sp : sq;
+            auto &prev = (u & 1) ? sq : sp;
+            read_view(boff, u, 0, 0);
+            if constexpr (VT > 1) read_view(boff, u, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (u > 0) agg_half(prev, std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int v = 0; v < VT; ++v) {
+                if (v == VH && u > 0) {
+                    agg_half(prev, std::integral_constant<int, 1>{});
+                    if (u == 1 && !(kWsExp & 4)) bare_barrier();                 // B: the memory waves have read the previous quad's results
+                    write_results(u - 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    cur[i][v] = bilerp(T[v & 1][0].v[i], T[v & 1][1].v[i], T[v & 1][2].v[i], T[v & 1][3].v[i], w00[u][v], w01[u][v], w10[u][v], w11[u][v]);
+                    asm volatile("" : "+v"(cur[i][v]));                           // fold HERE: keeps the tap registers short-lived
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (v + 2 < VT) read_view(boff, u, v + 2, v & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // the quad's last job (u = NVOX - 1, odd: its samples are in sp)
+        agg_half(sp, std::integral_constant<int, 0>{});
+        agg_half(sp, std::integral_constant<int, 1>{});
+        if constexpr (NVOX == 1) lds_barrier();
+        write_results(NVOX - 1);
+        lds_barrier();                                                           // results written; A of the next quad
+    };
+    lds_barrier();                                                               // zero regions written; A(0)
+    for (int q = 0; q < nq; q += 2) {
+        quad_iter(std::integral_constant<int, 0>{});
+        if (q + 1 < nq) quad_iter(std::integral_constant<int, kWsBufBytes>{});
+    }
+}
+
+// ---- host side
+inline bool brick_fwd_ws_shape_impl(const Problem &p)
+{
+    // 3 or 4 views, fp32 volume, z rows of whole 16-B quads, enough bricks to fill the chip (fewer: k_fwd_brick splits the channels)
+    if (brick_view_slots(p.V) != 4 || p.out_f16 || p.out_bf16 || (p.Z & 3) || p.X <= kBX) return false;
+    const long long bricks = (long long)((p.X + 7) / 8) * ((p.Y + 7) / 8) * ((p.Z + kBZ - 1) / kBZ) * p.B;
+    return bricks >= 256;
+}
+
+template <int METHOD, bool PRE>
+hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const Coords &coords, float *out, const Problem &p, hipStream_t s)
+{
+    constexpr int VT = 4;
+    const int nbx = (p.X + 7) / 8, nby = (p.Y + 7) / 8, nbz = (p.Z + kBZ - 1) / kBZ;
+    const int bps = nbx * nby * nbz, total = bps * p.B;
+    const size_t lds = (size_t)kWsLdsBytes + sizeof(FwdShared<VT>);
+    auto kern = k_fwd_ws<METHOD, VT, float, PRE>;
+    hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
+    if (e != hipSuccess) return e;
+    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
+    const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;   // tile work items x 8 XCDs x samples
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWsThreads), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, total, p.V,
+                       make_gate(p, true));
+    return hipGetLastError();
+}
+
+}  // namespace mvhmr

@@ -70,7 +70,7 @@ int check_desc(const mvhmr_unproject_desc *d, Problem *p)
         return fail(MVHMR_ERR_UNSUPPORTED, "bf16 is a storage type of the volume only (out_dtype); features are fp32 or fp16");
     if (d->out_dtype == MVHMR_BF16 && d->feat_dtype != MVHMR_F32)
         return fail(MVHMR_ERR_UNSUPPORTED, "a bf16 volume needs fp32 features");
-    if (d->feat_layout < 0 || d->feat_layout > MVHMR_LAYOUT_QUAD) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown feature layout %d", d->feat_layout);
+    if (d->feat_layout < 0 || d->feat_layout > MVHMR_LAYOUT_QUAD_LOG2E) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown feature layout %d", d->feat_layout);
     if (d->variant < 0 || d->variant > MVHMR_VARIANT_BRICK) return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown kernel variant %d", d->variant);
     if (d->views > kMaxViews) return fail(MVHMR_ERR_UNSUPPORTED, "at most %d views are supported (got %d)", kMaxViews, d->views);
     if (d->feat_dtype == MVHMR_F32 && d->out_dtype == MVHMR_F16)
@@ -283,6 +283,7 @@ int mvhmr_unproject_backward_supported(const mvhmr_unproject_desc *desc)
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
+    if (desc->feat_layout == MVHMR_LAYOUT_QUAD_LOG2E) return 0;                  // a forward-only layout
     if (desc->variant == MVHMR_VARIANT_BRICK && !bwd_uses_brick(desc, p)) return 0;
     if (desc->feat_layout == MVHMR_LAYOUT_QUAD && !bwd_uses_brick(desc, p) && !quad_to_channels_last_supported(p)) return 0;
     if (desc->feat_layout == MVHMR_LAYOUT_QUAD && desc->variant == MVHMR_VARIANT_GATHER && !quad_to_channels_last_supported(p)) return 0;
@@ -293,7 +294,7 @@ size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc)
 {
     Problem p;
     if (check_desc(desc, &p) != MVHMR_OK) return 0;
-    if (desc->feat_layout == MVHMR_LAYOUT_BVHWC) return 0;
+    if (desc->feat_layout == MVHMR_LAYOUT_BVHWC || desc->feat_layout == MVHMR_LAYOUT_QUAD_LOG2E) return 0;
     if (geometry_gated(desc, p)) return conv_bytes(p) + kGateBytes;   // one converted copy (either layout) + the gate counter
     if (desc->feat_layout == MVHMR_LAYOUT_QUAD) return pick_variant(desc, p) == MVHMR_VARIANT_BRICK ? 0 : featT_bytes(p);
     return pick_variant(desc, p) == MVHMR_VARIANT_BRICK ? brick_workspace_bytes(p) : featT_bytes(p);
@@ -302,7 +303,7 @@ size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc)
 size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc)
 {
     Problem p;
-    if (check_desc(desc, &p) != MVHMR_OK) return 0;
+    if (check_desc(desc, &p) != MVHMR_OK || desc->feat_layout == MVHMR_LAYOUT_QUAD_LOG2E) return 0;
     if (geometry_gated_bwd(desc, p) && bwd_uses_brick(desc, p)) return conv_bytes(p) + bwd_mid_bytes(desc, p) + kGateBytes;
     if (bwd_uses_brick(desc, p)) return brick_workspace_bytes(p) + gradT_bytes(p);
     if (bwd_uses_plane(desc, p)) return (desc->feat_layout == MVHMR_LAYOUT_BVCHW ? brick_workspace_bytes(p) : 0) + align_up(plane_table_bytes(p));
@@ -317,11 +318,25 @@ static int forward_impl(const mvhmr_unproject_desc *desc, Problem &p, const void
     int rc;
     if (!features || !proj || !out) return fail(MVHMR_ERR_INVALID_ARGUMENT, "features / proj / out must be non-null");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    mvhmr_unproject_desc dq;
+    if (desc->feat_layout == MVHMR_LAYOUT_QUAD_LOG2E) {
+        // the quad-planar copy times log2(e): only the wave-specialised softmax forward reads it (mvhmr_preferred_layout says when)
+        if (!brick_fwd_prescales(p) || desc->variant == MVHMR_VARIANT_GATHER)
+            return fail(MVHMR_ERR_UNSUPPORTED, "MVHMR_LAYOUT_QUAD_LOG2E feeds the softmax brick forward of 3 / 4 views with an fp32 volume only "
+                                               "(ask mvhmr_preferred_layout)");
+        dq = *desc;
+        dq.feat_layout = MVHMR_LAYOUT_QUAD;
+        dq.variant = MVHMR_VARIANT_BRICK;
+        desc = &dq;
+        p.feat_log2e = 1;
+    }
     const int variant = pick_variant(desc, p);
     rc = variant_conflict(desc, p, variant);
     if (rc != MVHMR_OK) return rc;
     rc = check_ws(workspace, workspace_bytes, mvhmr_unproject_forward_workspace_bytes(desc));
     if (rc != MVHMR_OK) return rc;
+    // planar input whose staged copy this call makes itself: scaled by log2(e) when the kernel that reads it wants that
+    if (desc->feat_layout == MVHMR_LAYOUT_BVCHW && brick_fwd_prescales(p)) p.feat_log2e = 1;
 
     if (geometry_gated(desc, p)) {
         // both variants are launched; the device-side brick count lets exactly one of them (and its layout pass) run
@@ -389,6 +404,8 @@ static int backward_impl(const mvhmr_unproject_desc *desc, Problem &p, const voi
     int rc;
     if (!grad_out || !features || !proj || !grad_features)
         return fail(MVHMR_ERR_INVALID_ARGUMENT, "grad_out / features / proj / grad_features must be non-null");
+    if (desc->feat_layout == MVHMR_LAYOUT_QUAD_LOG2E)
+        return fail(MVHMR_ERR_UNSUPPORTED, "MVHMR_LAYOUT_QUAD_LOG2E is a forward-only layout: hand the backward the features as they are");
     if (desc->feat_layout == MVHMR_LAYOUT_QUAD && !bwd_uses_brick(desc, p) && !quad_to_channels_last_supported(p))
         return fail(MVHMR_ERR_UNSUPPORTED, "backward from quad-planar features of this shape needs the brick backward (fp32, 2 / 4 / 8 views)");
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
@@ -513,7 +530,8 @@ int mvhmr_preferred_layout(const mvhmr_unproject_desc *desc)
     if (check_desc(&d, &p) != MVHMR_OK) return -1;
     const int variant = pick_variant(&d, p);
     if (variant_conflict(&d, p, variant) != MVHMR_OK) return -1;
-    return variant == MVHMR_VARIANT_BRICK ? MVHMR_LAYOUT_QUAD : MVHMR_LAYOUT_BVHWC;
+    if (variant != MVHMR_VARIANT_BRICK) return MVHMR_LAYOUT_BVHWC;
+    return brick_fwd_prescales(p) ? MVHMR_LAYOUT_QUAD_LOG2E : MVHMR_LAYOUT_QUAD;
 }
 
 size_t mvhmr_feature_layout_bytes(const mvhmr_unproject_desc *desc, int dst_layout)
@@ -524,7 +542,7 @@ size_t mvhmr_feature_layout_bytes(const mvhmr_unproject_desc *desc, int dst_layo
     d.feat_layout = MVHMR_LAYOUT_BVCHW;
     if (check_desc(&d, &p) != MVHMR_OK) return 0;
     if (dst_layout == MVHMR_LAYOUT_BVHWC) return featT_bytes(p);
-    if (dst_layout == MVHMR_LAYOUT_QUAD && p.C4 == p.C) return brick_workspace_bytes(p);   // always fp32, whatever the storage type
+    if ((dst_layout == MVHMR_LAYOUT_QUAD || dst_layout == MVHMR_LAYOUT_QUAD_LOG2E) && p.C4 == p.C) return brick_workspace_bytes(p);   // always fp32, whatever the storage type
     return 0;
 }
 
@@ -546,6 +564,10 @@ int mvhmr_convert_features(const mvhmr_unproject_desc *desc, const void *feature
     }
     if (dst_layout == MVHMR_LAYOUT_BVHWC) return launched(launch_to_channels_last(features, dst, p, s), "layout pass");
     if (dst_layout == MVHMR_LAYOUT_QUAD) return launched(launch_to_quad_planar_t(features, dst, p, s), "layout pass");
+    if (dst_layout == MVHMR_LAYOUT_QUAD_LOG2E) {
+        p.feat_log2e = 1;
+        return launched(launch_to_quad_planar_t(features, dst, p, s), "layout pass");
+    }
     return fail(MVHMR_ERR_INVALID_ARGUMENT, "unknown destination layout %d", dst_layout);
 }
 

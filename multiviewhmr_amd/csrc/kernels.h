@@ -15,6 +15,7 @@ struct Problem {
     int method;               // AGG_*
     int feat_f16, out_f16;    // storage types
     int out_bf16 = 0;         // the volume (out / grad_out) is bf16; features are fp32 then
+    int feat_log2e = 0;       // forward, quad-planar copy: the staged features are multiplied by log2(e) (brick_fwd_prescales)
     // Geometry gate (AUTO on planar input, shapes both variants serve): `gate_count` points at a device counter of
     // bricks whose windows overflow LDS (k_brick_gate); a gated kernel runs when (count <= gate_limit) == wants_brick
     // and returns at once otherwise.  Null = no gate.
@@ -52,6 +53,8 @@ hipError_t launch_bwd_gather(const void *grad_out, const void *featT, const floa
 //   forward : column-major quad-planar staged copy (launch_to_quad_planar_t), 4*nvox x (NT/128) x 32 bricks
 //   backward: the same column-major quad-planar staged copy, 8 x 8 x 16 (8 x 4 x 16 for 8 views) or 4 x (NT/128) x 32 bricks
 bool brick_fwd_supported(const Problem &p);
+bool brick_fwd_ws_shape(const Problem &p);      // the wave-specialised forward serves this problem
+bool brick_fwd_prescales(const Problem &p);     // ... and wants its staged copy multiplied by log2(e): set Problem::feat_log2e for BOTH the layout pass and the kernel
 bool brick_bwd_supported(const Problem &p);
 size_t brick_workspace_bytes(const Problem &p);
 hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s, bool brick_side = true);

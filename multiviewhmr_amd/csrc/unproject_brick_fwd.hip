@@ -1,6 +1,6 @@
 // Host side of the brick forward (kernel: brick_fwd_kernel.h, instantiated per aggregation method in unproject_brick_fwd_m*.hip),
 // the layout passes that build the staged fp32 copies, and the geometry gate.
-#include "brick_fwd_kernel.h"
+#include "brick_fwd_ws.h"
 
 namespace mvhmr {
 
@@ -10,7 +10,7 @@ namespace mvhmr {
 // 512-B runs along y.  fp16 features are widened here once instead of per tap in the kernel.
 template <typename TF>
 __global__ void __launch_bounds__(256)
-k_to_quad_planar_t(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int H, int W, Gate gate)
+k_to_quad_planar_t(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int H, int W, float scale, Gate gate)
 {
     if (gated_off(gate)) return;
     __shared__ float tile[4][32][33];                                           // [c][y][x], x padded: conflict-free both ways
@@ -25,7 +25,7 @@ k_to_quad_planar_t(const TF *__restrict__ src, float4 *__restrict__ dst, int C, 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int y = y0 + ty + 8 * i, x = x0 + tx;
-            if (y < H && x < W) tile[c][ty + 8 * i][tx] = to_f32<TF>(s[(long long)c * H * W + (long long)y * W + x]);
+            if (y < H && x < W) tile[c][ty + 8 * i][tx] = to_f32<TF>(s[(long long)c * H * W + (long long)y * W + x]) * scale;
         }
     __syncthreads();
     float4 *d = dst + (bv * (C >> 2) + q) * (long long)H * W;
@@ -40,7 +40,7 @@ k_to_quad_planar_t(const TF *__restrict__ src, float4 *__restrict__ dst, int C, 
 // linearly (1-KiB runs per wave instruction instead of 128-B tile rows) and written as 512-B runs along y.
 template <typename TF>
 __global__ void __launch_bounds__(512)
-k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int H, int W, int src_aligned, Gate gate)
+k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, int C, int H, int W, int src_aligned, float scale, Gate gate)
 {
     if (gated_off(gate)) return;
     extern __shared__ float band[];                                              // [c][y][x], row stride W | 1
@@ -83,24 +83,26 @@ k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, in
     const int ty = threadIdx.x & 31;
     if (ty < rows)
         for (int x = threadIdx.x >> 5; x < W; x += 16)
-            d[(long long)x * H + y0 + ty] = make_float4(band[ty * ldw + x], band[(32 + ty) * ldw + x], band[(64 + ty) * ldw + x], band[(96 + ty) * ldw + x]);
+            d[(long long)x * H + y0 + ty] = make_float4(band[ty * ldw + x] * scale, band[(32 + ty) * ldw + x] * scale, band[(64 + ty) * ldw + x] * scale,
+                                                        band[(96 + ty) * ldw + x] * scale);   // scale = 1 (exact) or log2(e) for the softmax forward
 }
 
 hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s, bool brick_side)
 {
     if (p.C % 4) return hipErrorNotSupported;
+    const float scale = p.feat_log2e ? kLog2e : 1.f;
     const Gate gate = make_gate(p, brick_side);
     const size_t band_bytes = (size_t)4 * 32 * (p.W | 1) * sizeof(float);
     if (band_bytes <= 64 * 1024) {                                               // 2+ blocks per CU
         const dim3 grid((p.H + 31) / 32, p.C / 4, p.B * p.V);
         const int aligned = (reinterpret_cast<uintptr_t>(src) % (p.feat_f16 ? 8 : 16)) == 0;
-        if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t_band<__half>, grid, dim3(512), band_bytes, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, aligned, gate);
-        else hipLaunchKernelGGL(k_to_quad_planar_t_band<float>, grid, dim3(512), band_bytes, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, aligned, gate);
+        if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t_band<__half>, grid, dim3(512), band_bytes, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, aligned, scale, gate);
+        else hipLaunchKernelGGL(k_to_quad_planar_t_band<float>, grid, dim3(512), band_bytes, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, aligned, scale, gate);
         return hipGetLastError();
     }
     const dim3 grid(((p.W + 31) / 32) * ((p.H + 31) / 32), p.C / 4, p.B * p.V);
-    if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, gate);
-    else hipLaunchKernelGGL(k_to_quad_planar_t<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, gate);
+    if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, scale, gate);
+    else hipLaunchKernelGGL(k_to_quad_planar_t<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, scale, gate);
     return hipGetLastError();
 }
 
@@ -171,8 +173,23 @@ bool brick_fwd_supported(const Problem &p)
     return true;
 }
 
+// the wave-specialised kernel (brick_fwd_ws.h) serves 3 / 4 views with an fp32 volume when the launch fills the chip
+#ifndef MVHMR_NO_WS
+#define MVHMR_NO_WS 0
+#endif
+bool brick_fwd_ws_shape(const Problem &p) { return !MVHMR_NO_WS && brick_fwd_supported(p) && brick_fwd_ws_shape_impl(p); }
+// its softmax reads a copy of the features multiplied by log2(e): the layout pass in front of it scales (Problem::feat_log2e)
+bool brick_fwd_prescales(const Problem &p) { return brick_fwd_ws_shape(p) && p.method == AGG_SOFTMAX; }
+
 GateGeom brick_fwd_gate_geom(const Problem &p)
 {
+    if (brick_fwd_ws_shape(p)) {
+        GateGeom g;
+        g.bx = 8; g.by = 8; g.bz = kBZ; g.column_major = 1; g.parity_rows = 1; g.view_group = 0;
+        g.cap_slots = kWsCapSlots;
+        g.max_chunks = kWsChunks * kWsMemWaves;
+        return g;
+    }
     const int nt = brick_fwd_grouped(p) ? 1024 : fwd_threads(p.V);
     GateGeom g;
     g.bx = kBX * brick_fwd_nvox(p); g.by = nt / 128; g.bz = kBZ; g.column_major = 1;

@@ -1,5 +1,5 @@
 // k_fwd_brick instantiations for aggregation method 1 (one translation unit per method: parallel builds)
-#include "brick_fwd_groups.h"
+#include "brick_fwd_ws.h"
 namespace mvhmr {
 template hipError_t launch_fwd_method<1>(const void *, const float *, const Coords &, void *, const Problem &, int, hipStream_t);
 }
