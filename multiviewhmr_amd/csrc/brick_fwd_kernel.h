@@ -156,6 +156,26 @@ __device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const floa
     if constexpr (kExp & (16 | 128)) {
         ra = fwd_aggregate<METHOD, VT>(sa);
         rb = fwd_aggregate<METHOD, VT>(sb);
+#ifdef MVHMR_EXP_OLDPRE
+    } else if constexpr (METHOD == AGG_SOFTMAX && VT == 4) {
+        // timing experiment: the prescaled softmax of brick_fwd_ws.h in k_fwd_brick
+        float ta[VT], tb[VT];
+#pragma unroll
+        for (int v = 1; v < VT; ++v) { ta[v] = sa[v] - sa[0]; tb[v] = sb[v] - sb[0]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 1; v < VT; ++v) { ta[v] = __builtin_amdgcn_exp2f(ta[v]); tb[v] = __builtin_amdgcn_exp2f(tb[v]); }
+        __builtin_amdgcn_sched_barrier(0);
+        float da = 1.f, db = 1.f, na = sa[0], nb = sb[0];
+#pragma unroll
+        for (int v = 1; v < VT; ++v) { da += ta[v]; na = fmaf(ta[v], sa[v], na); db += tb[v]; nb = fmaf(tb[v], sb[v], nb); }
+        __builtin_amdgcn_sched_barrier(0);
+        float ia = __builtin_amdgcn_rcpf(da), ib = __builtin_amdgcn_rcpf(db);
+        __builtin_amdgcn_sched_barrier(0);
+        ia *= 0.6931471805599453f; ib *= 0.6931471805599453f;
+        ra = na * ia; rb = nb * ib;
+        if (__builtin_amdgcn_ballot_w64(!(da + db < 1.152921504606847e18f)) != 0) { ra = aggregate<METHOD, VT>(sa); rb = aggregate<METHOD, VT>(sb); }
+#endif
     } else {
         aggregate2<METHOD, VT>(sa, sb, ra, rb);
     }
@@ -716,7 +736,9 @@ hipError_t launch_fwd_method(const void *featK_, const float *proj, const Coords
         if (p.feat_log2e) return hipErrorNotSupported;
         return launch_fwd_ws_instance<METHOD, false>(featK, proj, coords, (float *)out, p, s);
     }
+#ifndef MVHMR_EXP_OLDPRE
     if (p.feat_log2e) return hipErrorNotSupported;                               // only the wave-specialised softmax reads a prescaled copy
+#endif
 #define MVHMR_FWD_CASE(NVIEWS, NTHR, NV)                                                                                                 \
     if (brick_view_slots(p.V) == NVIEWS && nvox == NV)                                                                                                   \
         return p.out_f16    ? launch_fwd_instance<METHOD, NVIEWS, NTHR, __half, NV>(featK, proj, coords, (__half *)out, p, s)            \

@@ -32,16 +32,20 @@
 
 namespace mvhmr {
 
-constexpr int kWsThreads = 768, kWsMemWaves = 4, kWsCompWaves = 8, kWsNvox = 4;
+constexpr int kWsMemWaves = 4;
+#ifndef MVHMR_WS_CFG
+#define MVHMR_WS_CFG 1                                                            // wave layout of k_fwd_ws (see the kernel)
+#endif
 constexpr int kWsBufBytes = 64512;                                   // window buffer: zero region + 3 904 slots; < 65 536: a DS offset
 constexpr int kWsCapSlots = (kWsBufBytes - kZeroBytes) / 16;
 constexpr int kWsResBytes = 4 * 64 * 32 * 4;                         // R[channel][column = x * 8 + y][z] fp32
 constexpr int kWsLdsBytes = 2 * kWsBufBytes + kWsResBytes;           // FwdShared<VT> behind it
-constexpr int kWsChunks = 16;                                        // LDS-DMA pieces per memory wave and quad (64 x 64 slots >= cap)
-static_assert(kWsCapSlots % 64 == 0 && kWsCapSlots <= kWsChunks * kWsMemWaves * 64, "window pool / chunk table");
+constexpr int kWsSyncOff = kWsLdsBytes + 1024;                       // one LDS word behind FwdShared: the memory waves' "R has been read" counter
+constexpr int kWsChunkTotal = 64;                                    // LDS-DMA pieces per quad (64 x 64 slots >= cap), dealt to the memory waves
+static_assert(kWsCapSlots % 64 == 0 && kWsCapSlots <= kWsChunkTotal * 64, "window pool / chunk table");
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 #ifndef MVHMR_WS_EXP
-#define MVHMR_WS_EXP 0                                                            // timing-only (scripts/exp): 1 no LDS-DMA / stores, 2 no arithmetic, 4 no barrier B
+#define MVHMR_WS_EXP 0                                                            // timing-only (scripts/exp): 1 no LDS-DMA / stores, 2 no arithmetic, 4 no barrier B, 8 no stores, 16 no LDS-DMA
 #endif
 constexpr int kWsExp = MVHMR_WS_EXP;
 
@@ -174,136 +178,136 @@ __device__ __attribute__((noinline)) void ws_slow_voxel(const float4 *fk, TO *ob
     }
 }
 
-template <int METHOD, int VT, typename TO, bool PRE>
-__global__ void __launch_bounds__(kWsThreads)
-k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords, TO *__restrict__ out, int C, int H, int W,
-         int X, int Y, int Z, int nby, int nbz, int bricks_per_sample, int total_blocks, int nv, Gate gate)
+// ds_write_b32 at an LDS byte address + immediate offset (outside hipcc's lgkmcnt bookkeeping: see write_half)
+template <int OFF>
+__device__ __forceinline__ void lds_write_at(unsigned addr, float v)
 {
-    // nv <= VT views are real (3 views run the 4-view kernel): the others have no camera, no window and no part in the aggregate --
-    // their samples read kAbsentSample from a slot of the zero region (softmax, max) or plain zeros (sum, mean)
-    if (gated_off(gate)) return;
-    static_assert(sizeof(TO) == 4, "fp32 volumes (16-bit volumes: k_fwd_brick)");
-    static_assert(!PRE || METHOD == AGG_SOFTMAX, "only the softmax reads a prescaled copy");
-    constexpr int NVOX = kWsNvox, NMW = kWsMemWaves, BX = 8, BY = 8;
-    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
-    extern __shared__ __align__(16) unsigned char smem[];
-    FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + kWsLdsBytes);
-    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
-    const bool memw = wave < NMW;
+    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
 
-    // XCD-aware order as in k_fwd_brick (speed only): blocks i, i + 8, ... share an XCD under round-robin dispatch; all eight XCDs work
-    // on the same sample, each on a compact tile of brick columns (all z)
-    const int nbx = bricks_per_sample / (nby * nbz);
-    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
-    const int tw = (nbx + tiles_x - 1) / tiles_x, th = (nby + tiles_y - 1) / tiles_y;
-    const int share = tw * th * nbz;
-    const int bid = (int)blockIdx.x, xcd = bid & 7, j = bid >> 3;
-    const int b = j / share, r = j % share;
-    const int kz = r % nbz, cy = (r / nbz) % th, cx = r / (nbz * th);
-    const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
-    if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
-    const long long N = (long long)X * Y * Z;
-    const int HW = H * W, nq = C >> 2;
-    TO *const obase = out + (long long)b * C * N;
-    const float4 *const fk = featK + (long long)b * nv * nq * HW;
-    const unsigned chan_bytes = (unsigned)(N * sizeof(TO));
-    const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
+// what both roles of a block know about their brick
+template <typename TO>
+struct WsBrick {
+    const float4 *fk;            // staged features of this sample, quad 0
+    TO *obase;                   // output of this sample, channel 0
+    long long N;
+    int b, kx, ky, kz, nq, H, W, X, Y, Z, nv;
+    unsigned chan_bytes, lds_base;
+};
 
-    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
-    if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
-    __syncthreads();
-
-    if (memw) {
-        // ================================================================ memory waves
-        __syncthreads();                                                         // the compute waves' boxes are complete
-        WsWindows<VT> win;
-        ws_size_windows<VT>(sh, win);
-        if (!win.fits) return;                                                   // the compute waves sample from global memory
-        // ---- LDS-DMA pieces of this wave: piece c = wave + 4 rr covers 64 consecutive slots of one view's window (the views are
-        // packed back to back in 64-slot chunks, so piece c lands at slot 64 c of the buffer)
-        unsigned go[kWsChunks];
-        int n_m = 0;
+// ==================================================================== memory waves (NMW of them; wave = 0 .. NMW - 1)
+template <int VT, typename TO, int NMW>
+__device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdShared<VT> *sh, const WsBrick<TO> &B, int wave, int lane)
+{
+    constexpr int MC = kWsChunkTotal / NMW, NS = 32 / NMW;                       // pieces / store instructions per wave and quad
+    WsWindows<VT> win;
+    ws_size_windows<VT>(sh, win);
+    if (!win.fits) return;                                                       // the compute waves sample from global memory
+    const int HW = B.H * B.W;
+    // ---- LDS-DMA pieces of this wave: piece c = wave + NMW rr covers 64 consecutive slots of one view's window (the views are
+    // packed back to back in 64-slot chunks, so piece c lands at slot 64 c of the buffer)
+    unsigned go[MC];
+    int n_m = 0;
 #pragma unroll
-        for (int rr = 0; rr < kWsChunks; ++rr) {
-            const int c = wave + rr * NMW;
-            go[rr] = 0;
-            if (c < win.nch[VT]) {
-                int v = 0;
+    for (int rr = 0; rr < MC; ++rr) {
+        const int c = wave + rr * NMW;
+        go[rr] = 0;
+        if (c < win.nch[VT]) {
+            int v = 0;
 #pragma unroll
-                for (int uu = 1; uu < VT; ++uu) v += c >= win.nch[uu] ? 1 : 0;
-                int sv = win.ws[0], ox = win.wx0[0], oy = win.wy0[0], c0 = win.nch[0], hv = win.whp[0];
+            for (int uu = 1; uu < VT; ++uu) v += c >= win.nch[uu] ? 1 : 0;
+            int sv = win.ws[0], ox = win.wx0[0], oy = win.wy0[0], c0 = win.nch[0], hv = win.whp[0];
 #pragma unroll
-                for (int uu = 1; uu < VT; ++uu) if (v == uu) { sv = win.ws[uu]; ox = win.wx0[uu]; oy = win.wy0[uu]; c0 = win.nch[uu]; hv = win.whp[uu]; }
-                const int slot = ((c - c0) << 6) + lane;
-                const int px = slot / sv;
-                int py = slot - px * sv;
-                py = py >= hv ? 2 * (py - hv) + 1 : 2 * py;                      // slot inside the column -> row (even rows first)
-                int gx = ox + px, gy = oy + py;                                  // pad rows / columns past the window / outside the
-                gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);                     // image: clamp -- those slots only meet zero weights
-                gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
-                go[rr] = (unsigned)((v * nq) * HW + gx * H + gy) * 16u;
-                ++n_m;
-            }
+            for (int uu = 1; uu < VT; ++uu) if (v == uu) { sv = win.ws[uu]; ox = win.wx0[uu]; oy = win.wy0[uu]; c0 = win.nch[uu]; hv = win.whp[uu]; }
+            const int slot = ((c - c0) << 6) + lane;
+            const int px = slot / sv;
+            int py = slot - px * sv;
+            py = py >= hv ? 2 * (py - hv) + 1 : 2 * py;                          // slot inside the column -> row (even rows first)
+            int gx = ox + px, gy = oy + py;                                      // pad rows / columns past the window / outside the
+            gx = gx < 0 ? 0 : (gx > B.W - 1 ? B.W - 1 : gx);                     // image: clamp -- those slots only meet zero weights
+            gy = gy < 0 ? 0 : (gy > B.H - 1 ? B.H - 1 : gy);
+            go[rr] = (unsigned)((v * B.nq) * HW + gx * B.H + gy) * 16u;
+            ++n_m;
         }
-        const float4 *src_n = fk;                                                // plane of the next quad to request
-        auto dma = [&](int boff) __attribute__((always_inline)) {
+    }
+    const float4 *src_n = B.fk;                                                  // plane of the next quad to request
+    auto dma = [&](int boff) __attribute__((always_inline)) {
 #pragma unroll
-            for (int rr = 0; rr < kWsChunks; ++rr)
-                if (rr < n_m && !(kWsExp & 1)) glds16_m0(src_n, go[rr], lds_base + (unsigned)(boff + kZeroBytes + (wave + rr * NMW) * 1024));
-            src_n += HW;
-        };
-        // ---- stores: instruction j = wave + 4 k (k < 8) writes channel j >> 3, brick column x = j & 7: lane = (y, z quad) reads
-        // R[j >> 3][(j & 7) * 8 + y][4 z4 ..] (1 KiB contiguous per instruction) and writes 16 B; 8 lanes = one 128-B row
-        const int yl = lane >> 3, z4 = lane & 7;
-        const int vy = ky * BY + yl, vz = kz * kBZ + z4 * 4;
-        const unsigned voff = (vy < Y && vz < Z) ? (unsigned)((((long long)(kx * BX) * Y + vy) * Z + vz) * (long long)sizeof(TO)) : 0xFFFFFFF0u;   // beyond num_records: dropped
-        const unsigned xstep = (unsigned)((long long)Y * Z * sizeof(TO));
-        int n_st = 0;                                                            // store instructions of this wave per quad
+        for (int rr = 0; rr < MC; ++rr)
+            if (rr < n_m && !(kWsExp & (1 | 16))) glds16_m0(src_n, go[rr], B.lds_base + (unsigned)(boff + kZeroBytes + (wave + rr * NMW) * 1024));
+        src_n += HW;
+    };
+    // ---- stores: instruction j = wave + NMW k (k < NS) writes channel j >> 3, brick row y = j & 7: lane = (x, z quad) reads
+    // R[j >> 3][(j & 7) * 8 + x][4 z4 ..] (1 KiB contiguous per instruction) and writes 16 B; 8 lanes = one 128-B run of z
+    const int xl = lane >> 3, z4 = lane & 7;
+    const int vx = B.kx * 8 + xl, vz = B.kz * kBZ + z4 * 4;
+    const unsigned voff = (vx < B.X && vz < B.Z) ? (unsigned)((((long long)vx * B.Y + B.ky * 8) * B.Z + vz) * (long long)sizeof(TO)) : 0xFFFFFFF0u;   // beyond num_records: dropped
+    const unsigned ystep = (unsigned)(B.Z * (int)sizeof(TO));
+    int n_st = 0;                                                                // store instructions of this wave per quad
 #pragma unroll
-        for (int k = 0; k < 8; ++k) n_st += kx * BX + ((wave + 4 * k) & 7) < X ? 1 : 0;
-        const int r_rd = kWsResBytes == 0 ? 0 : 2 * kWsBufBytes + wave * 1024 + lane * 16;
-        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    for (int k = 0; k < NS; ++k) n_st += B.ky * 8 + ((wave + NMW * k) & 7) < B.Y ? 1 : 0;
+    const int r_rd = 2 * kWsBufBytes + wave * 1024 + lane * 16;
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-        dma(0);                                                                  // quad 0 -> buffer 0
-        for (int q = 0; q <= nq; ++q) {
-            // the pieces of quad q have landed: younger than them are only the n_st stores issued behind them (none before quad 2)
-            if (q < nq) {
-                if (q < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else wait_vmcnt_ladder<0, 8, 8>(n_st);
-            }
-            bare_barrier();                                                      // A(q): windows of quad q published; results of quad q - 1 complete
-            float4 res[8];
-            if (q > 0) {
+    dma(0);                                                                      // quad 0 -> buffer 0
+    for (int q = 0; q <= B.nq; ++q) {
+        // the pieces of quad q have landed: younger than them are only the n_st stores issued behind them (none before quad 2)
+        if (q < B.nq) {
+            if (q < 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else wait_vmcnt_ladder<0, NS, NS>(n_st);
+        }
+        bare_barrier();                                                          // A(q): windows of quad q published; results of quad q - 1 complete
+        // (the only barrier of the quad loop: the hand-back "R may be overwritten" is a counter, see below)
+        float4 res[NS];
+        if (q > 0) {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) res[k] = *reinterpret_cast<const float4 *>(smem + r_rd + k * 4096);
-            }
-            if (q < nq) {
-                if constexpr (!(kWsExp & 4)) lds_barrier();                      // B(q): R has been read, the compute waves may write quad q's results
-                if (q + 1 < nq) dma(((q + 1) & 1) * kWsBufBytes);                // every wave has passed A(q): the other buffer is free
-            }
-            if (q > 0) {
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(obase + (long long)((q - 1) * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
+            for (int k = 0; k < NS; ++k) res[k] = *reinterpret_cast<const float4 *>(smem + r_rd + k * NMW * 1024);
+        }
+        if (q < B.nq) {
+            // R has been read (lgkmcnt(0)): tell the compute waves, which may then write quad q's results -- every lane adds 1, so the
+            // counter stands at 64 NMW q once all memory waves have read the results of quad q - 1.  No barrier: nobody waits here.
+            if (q > 0) asm volatile("s_waitcnt lgkmcnt(0)\n\tds_add_u32 %0, %1" : : "v"(kWsSyncOff), "v"(1) : "memory");
+            if (q + 1 < B.nq) dma(((q + 1) & 1) * kWsBufBytes);                  // every wave has passed A(q): the other buffer is free
+        }
+        if (q > 0) {
+            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(B.obase + (long long)((q - 1) * 4) * B.N, 0, (int)(4u * B.chan_bytes), 0x00020000);
+            if constexpr (kWsExp & 32) {
+                // timing only: the (brick, quad)'s 32 KiB of results as ONE contiguous region of the output buffer
+                const long long region = ((long long)blockIdx.x * B.nq + (q - 1)) * 8192;   // north-star shape: the grid has exactly one block per brick
+                rs = __builtin_amdgcn_make_buffer_rsrc(B.obase - (long long)B.b * (B.nq * 4) * B.N + region, 0, 32768, 0x00020000);
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int jj = wave + 4 * k, xs = jj & 7, ch = jj >> 3;
-                    if (kx * BX + xs < X && !(kWsExp & 1)) {
-                        const u32x4 d = {__builtin_bit_cast(unsigned, res[k].x), __builtin_bit_cast(unsigned, res[k].y),
-                                         __builtin_bit_cast(unsigned, res[k].z), __builtin_bit_cast(unsigned, res[k].w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)voff, (int)(xs * xstep + ch * chan_bytes), kStAux);
-                    }
+                for (int k = 0; k < NS; ++k) {
+                    const u32x4 d = {__builtin_bit_cast(unsigned, res[k].x), __builtin_bit_cast(unsigned, res[k].y),
+                                     __builtin_bit_cast(unsigned, res[k].z), __builtin_bit_cast(unsigned, res[k].w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs, lane * 16, (wave + NMW * k) * 1024, kStAux);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                const int jj = wave + NMW * k, ys = jj & 7, ch = jj >> 3;
+                if (B.ky * 8 + ys < B.Y && !(kWsExp & (1 | 8))) {
+                    const u32x4 d = {__builtin_bit_cast(unsigned, res[k].x), __builtin_bit_cast(unsigned, res[k].y),
+                                     __builtin_bit_cast(unsigned, res[k].z), __builtin_bit_cast(unsigned, res[k].w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)voff, (int)(ys * ystep + ch * B.chan_bytes), kStAux);
                 }
             }
         }
-        return;
     }
+}
 
-    // ==================================================================== compute waves
-    const int cw = wave - NMW;                                                   // brick row y
+// ==================================================================== compute waves: NVOX "units" (two x-adjacent columns x 32 z) each,
+// units u0 .. u0 + NVOX - 1 of the brick's 32 (unit = 4 y + x pair).  Ends with the barrier sequence the memory waves run.
+template <int METHOD, int VT, typename TO, bool PRE, int NVOX>
+__device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<VT> *sh, const WsBrick<TO> &B, const Coords &coords, int u0, int lane,
+                                                int ctid, int cthreads)
+{
+    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    const int nv = B.nv;
     int dcol, zin;
     fwd_lane_voxel<1>(lane, dcol, zin);                                          // lane = 32 * (x parity) + z (z quads permuted: LDS pass groups are z runs)
-    const int vy_r = ky * BY + cw, vz_r = kz * kBZ + zin;
-    const bool in_yz = vy_r < Y && vz_r < Z;
-    const int vy = vy_r < Y ? vy_r : Y - 1, vz = vz_r < Z ? vz_r : Z - 1;
+    const int vz_r = B.kz * kBZ + zin;
+    const int vz = vz_r < B.Z ? vz_r : B.Z - 1;
     unsigned vox[NVOX];
     bool inside[NVOX];
     float w00[NVOX][VT], w01[NVOX][VT], w10[NVOX][VT], w11[NVOX][VT];
@@ -316,15 +320,16 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
         for (int v = 0; v < VT; ++v) { bxmin[v] = big; bymin[v] = big; bxmax[v] = -big; bymax[v] = -big; }
 #pragma unroll
         for (int u = 0; u < NVOX; ++u) {
-            const int vx_r = kx * BX + dcol + 2 * u;
-            inside[u] = in_yz && vx_r < X;
-            const int vx = vx_r < X ? vx_r : X - 1;                              // outside the volume: the clamped edge voxel's centre, no part in the windows
-            vox[u] = (unsigned)(((long long)vx * Y + vy) * Z + vz);             // N < 2^28 (brick_fwd_supported)
+            const int unit = u0 + u;
+            const int vx_r = B.kx * 8 + 2 * (unit & 3) + dcol, vy_r = B.ky * 8 + (unit >> 2);
+            inside[u] = vx_r < B.X && vy_r < B.Y && vz_r < B.Z;
+            const int vx = vx_r < B.X ? vx_r : B.X - 1, vy = vy_r < B.Y ? vy_r : B.Y - 1;   // outside the volume: the clamped edge voxel's centre, no part in the windows
+            vox[u] = (unsigned)(((long long)vx * B.Y + vy) * B.Z + vz);         // N < 2^28 (brick_fwd_supported)
             float c0, c1, c2;
-            voxel_xyz(coords, b, N, vox[u], c0, c1, c2);
+            voxel_xyz(coords, B.b, B.N, vox[u], c0, c1, c2);
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
-                const Taps t = make_taps(sh->proj[v], c0, c1, c2, H, W);
+                const Taps t = make_taps(sh->proj[v], c0, c1, c2, B.H, B.W);
                 w00[u][v] = t.w00; w01[u][v] = t.w01; w10[u][v] = t.w10; w11[u][v] = t.w11;
                 tx[u][v] = t.rx0; ty[u][v] = t.ry0;
                 if (t.any && inside[u] && v < nv) {
@@ -352,26 +357,31 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
         // ---- windows do not fit the LDS pool: sample straight from global memory (the memory waves have left)
 #pragma unroll 1
         for (int u = 0; u < NVOX; ++u)
-            if (inside[u]) ws_slow_voxel<METHOD, VT, TO>(fk, obase, sh->proj, coords, b, N, vox[u], nq, nq, H, W, nv, PRE ? kLn2 : 1.f);
+            if (inside[u]) ws_slow_voxel<METHOD, VT, TO>(B.fk, B.obase, sh->proj, coords, B.b, B.N, vox[u], B.nq, B.nq, B.H, B.W, nv, PRE ? kLn2 : 1.f);
         return;
     }
 
     // zero regions at the head of both window buffers (samples that are identically zero read them); absent views: kAbsentSample
-    for (int i = tid - NMW * 64; i < kZeroSlots * 2; i += kWsCompWaves * 64) {
+    if (ctid == 0) *reinterpret_cast<int *>(smem + kWsSyncOff) = 0;
+    for (int i = ctid; i < kZeroSlots * 2; i += cthreads) {
         const float z = (kAbsentReads && nv < VT && i % kZeroSlots == kAbsentSlot) ? kAbsentSample : 0.f;
         *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * kWsBufBytes + (i % kZeroSlots) * 16) = make_float4(z, z, z, z);
     }
-    // ---- LDS byte offsets (inside a buffer) of the taps in column x0: a0 = the EVEN row of the footprint, a1 = the odd row; column
-    // x0 + 1 is one column stride further.  The weights are kept in that order (even row x0, even row x0 + 1, odd row x0, odd row
-    // x0 + 1): for an odd y0 the sum runs sw, se, nw, ne instead of ATen's nw, ne, sw, se -- <= 1 ulp of the sample.
-    // (both in one register: buffer-relative offsets are below 2^16)
+    // ---- LDS byte offsets (inside a buffer) of the taps in column x0: a0 = the EVEN row of the footprint, a1 = the odd row (both in
+    // one register: buffer-relative offsets are below 2^16); column x0 + 1 is one column stride further.  The weights are kept in that
+    // order (even row x0, even row x0 + 1, odd row x0, odd row x0 + 1): for an odd y0 the sum runs sw, se, nw, ne instead of ATen's
+    // nw, ne, sw, se -- <= 1 ulp of the sample.
     unsigned ap[NVOX][VT];
     int ws16[VT];
+    // the column strides: in VGPRs where registers allow (v_add_u32 v, v, v issues at the full rate, v, s, v at half); the three-unit
+    // waves of the 1 024-thread layout have none to spare and keep them scalar
+    constexpr bool kStrideVgpr = NVOX != 3;
 #pragma unroll
     for (int v = 0; v < VT; ++v) {
         int s16 = win.ws[v] * 16;
         if (kAbsentReads && v >= nv) s16 = 16;                                   // "one column further": the zero slot next to the absent sample
-        asm volatile("v_mov_b32 %0, %1" : "=v"(ws16[v]) : "s"(s16));           // in a VGPR: v_add_u32 v, v, v issues at the full rate, v, s, v at half
+        if constexpr (kStrideVgpr) asm volatile("v_mov_b32 %0, %1" : "=v"(ws16[v]) : "s"(s16));
+        else ws16[v] = s16;
 #pragma unroll
         for (int u = 0; u < NVOX; ++u) {
             const bool ok = (valid >> (u * VT + v)) & 1u;
@@ -390,21 +400,21 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
             ap[u][v] = (unsigned)a0 | ((unsigned)a1 << 16);
         }
     }
-    // R address of this lane's voxel u = 0, channel 0: column (x parity) * 8 + y; voxel u is 2 u columns of 8 x 32 floats further,
+    // R address of this lane's unit u0, channel 0: R[channel][column = 2 unit + x parity][z]; unit u0 + u is 256 u bytes further,
     // channel i 64 columns further: immediate offsets
-    const int rbase = 2 * kWsBufBytes + ((dcol * 8 + cw) * 32 + zin) * 4;
+    const int rbase = 2 * kWsBufBytes + ((2 * u0 + dcol) * 32 + zin) * 4;
 
     f32x4 T[2][4];
     float sq[4][VT], sp[4][VT], res[4];
     auto read_view = [&](auto boff, int u, int v, int set) __attribute__((always_inline)) {
         constexpr int BOFF = decltype(boff)::value;
-        unsigned pk = ap[u][v];
-        asm volatile("" : "+v"(pk));                                             // unpacked per use: hoisted out of the quad loop, the 64 addresses would spill
+        asm volatile("" : "+v"(ap[u][v]));                                       // unpacked per use: hoisted out of the quad loop, the addresses would spill
+        const unsigned pk = ap[u][v];
         const int base = (int)(pk & 0xFFFFu), base1 = (int)(pk >> 16), far = base + ws16[v], far1 = base1 + ws16[v];
         T[set][0] = lds_tap(smem, base + BOFF); T[set][2] = lds_tap(smem, base1 + BOFF);
         T[set][1] = lds_tap(smem, far + BOFF); T[set][3] = lds_tap(smem, far1 + BOFF);
     };
-    // the aggregate of one job in two halves (channels 0 / 1, then 2 / 3 + the job's overflow test)
+    // the aggregate of one job in two halves (channels 0 / 1, then 2 / 3)
     auto agg_half = [&](float (&s)[4][VT], auto half) __attribute__((always_inline)) {
         constexpr int h = decltype(half)::value;
         if constexpr (METHOD == AGG_SOFTMAX && VT > 1) {
@@ -422,38 +432,67 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
             res[2 * h + 1] = aggregate<METHOD, VT>(s[2 * h + 1]);
         }
     };
-    auto write_results = [&](int u) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float *>(smem + rbase + i * 8192 + u * 2048) = res[i];
+    // two of a job's four results.  ds_write_b32 with the (channel, unit) part of the address in the offset field, written as inline asm:
+    // left to the compiler the twelve addresses become twelve loop-invariant registers.  Outside its lgkmcnt bookkeeping, which is
+    // harmless (LDS operations retire in order: an unknown younger write only makes a counted wait cover more); lds_barrier() ends the quad.
+    auto write_half = [&](auto utag, auto htag) __attribute__((always_inline)) {
+        constexpr int u = decltype(utag)::value, h = decltype(htag)::value;
+        lds_write_at<(2 * h) * 8192 + u * 256>((unsigned)rbase, res[2 * h]);
+        lds_write_at<(2 * h + 1) * 8192 + u * 256>((unsigned)rbase, res[2 * h + 1]);
     };
 
-    // One quad.  Jobs u = 0 .. 3: request views 0 and 1, first half of the PREVIOUS job's aggregate, fold view 0 / request view 2,
-    // fold view 1 / request view 3, second half of the previous aggregate + its four results to R, fold views 2 and 3.  Barrier B sits in
-    // front of the quad's first write to R.  The last job is aggregated behind the loop, then lgkmcnt(0) + barrier A of the next quad.
-    constexpr int VH = (VT + 1) / 2;
+    // One quad.  Jobs u = 0 .. NVOX - 1: request views 0 and 1, first half of the PREVIOUS job's aggregate (two results to R), fold view 0 /
+    // request view 2, second half of the previous aggregate, fold view 1 / request view 3, fold views 2 and 3.  Barrier B sits in front of
+    // the quad's first write to R.  The last job is aggregated behind the loop, then lgkmcnt(0) + barrier A of the next quad.
+    // before a quad's first write to R: the memory waves must have read the previous quad's results (counter >= 64 NMW q).  The counter
+    // is requested at the head of the job and looked at here, behind sixteen tap reads: normally it has long been raised
+    // (ds_read_b32 as inline asm: through a volatile pointer hipcc makes it a FLAT load, whose wait drains every tap read in flight.
+    // LDS operations return in order, so with at most 15 younger ones outstanding -- lgkmcnt(15) -- the counter has arrived)
+    int r_need = 0;                                                              // 64 NMW q
+    auto read_r_counter = [&]() __attribute__((always_inline)) {
+        int seen;
+        asm volatile("ds_read_b32 %0, %1" : "=v"(seen) : "v"(kWsSyncOff) : "memory");
+        return seen;
+    };
+    auto wait_r_free = [&](int seen) __attribute__((always_inline)) {
+        if constexpr (kWsExp & 4) return;
+        asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(seen) : : "memory");
+        while (uniform(seen) < r_need) {
+            __builtin_amdgcn_s_sleep(1);
+            asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(seen) : "v"(kWsSyncOff) : "memory");
+        }
+    };
     auto quad_iter = [&](auto boff) __attribute__((always_inline)) {
         if constexpr (kWsExp & 2) {
-            if constexpr (!(kWsExp & 4)) bare_barrier();
-            write_results(0);
+            wait_r_free(read_r_counter());
+            write_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+            r_need += 64 * kWsMemWaves;
             lds_barrier();
             return;
         }
-#pragma unroll
-        for (int u = 0; u < NVOX; ++u) {
+        auto job = [&](auto utag) __attribute__((always_inline)) {
+            constexpr int u = decltype(utag)::value;
             auto &cur = (u & 1) ? sp : sq;
             auto &prev = (u & 1) ? sq : sp;
+            int seen = 0;
+            if constexpr (u == 1) seen = read_r_counter();
             read_view(boff, u, 0, 0);
             if constexpr (VT > 1) read_view(boff, u, 1, 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (u > 0) agg_half(prev, std::integral_constant<int, 0>{});
+            if constexpr (u > 0) {
+                agg_half(prev, std::integral_constant<int, 0>{});
+                if constexpr (u == 1) wait_r_free(seen);                         // the memory waves have read the previous quad's results
+                write_half(std::integral_constant<int, (u > 0 ? u - 1 : 0)>{}, std::integral_constant<int, 0>{});
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
-                if (v == VH && u > 0) {
-                    agg_half(prev, std::integral_constant<int, 1>{});
-                    if (u == 1 && !(kWsExp & 4)) bare_barrier();                 // B: the memory waves have read the previous quad's results
-                    write_results(u - 1);
-                    __builtin_amdgcn_sched_barrier(0);
+                if constexpr (u > 0) {
+                    if (v == (VT > 1 ? 1 : 0)) {
+                        agg_half(prev, std::integral_constant<int, 1>{});
+                        write_half(std::integral_constant<int, (u > 0 ? u - 1 : 0)>{}, std::integral_constant<int, 1>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -464,18 +503,80 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
                 if (v + 2 < VT) read_view(boff, u, v + 2, v & 1);
                 __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        // the quad's last job (u = NVOX - 1, odd: its samples are in sp)
-        agg_half(sp, std::integral_constant<int, 0>{});
-        agg_half(sp, std::integral_constant<int, 1>{});
-        if constexpr (NVOX == 1) lds_barrier();
-        write_results(NVOX - 1);
+        };
+        job(std::integral_constant<int, 0>{});
+        if constexpr (NVOX > 1) job(std::integral_constant<int, 1>{});
+        if constexpr (NVOX > 2) job(std::integral_constant<int, 2>{});
+        if constexpr (NVOX > 3) job(std::integral_constant<int, 3>{});
+        static_assert(NVOX <= 4, "jobs per quad");
+        // the quad's last job (its samples are in sq for an odd NVOX, in sp for an even one)
+        auto &last = ((NVOX - 1) & 1) ? sp : sq;
+        agg_half(last, std::integral_constant<int, 0>{});
+        if constexpr (NVOX == 1) wait_r_free(read_r_counter());
+        write_half(std::integral_constant<int, NVOX - 1>{}, std::integral_constant<int, 0>{});
+        agg_half(last, std::integral_constant<int, 1>{});
+        write_half(std::integral_constant<int, NVOX - 1>{}, std::integral_constant<int, 1>{});
+        r_need += 64 * kWsMemWaves;
         lds_barrier();                                                           // results written; A of the next quad
     };
     lds_barrier();                                                               // zero regions written; A(0)
-    for (int q = 0; q < nq; q += 2) {
+    for (int q = 0; q < B.nq; q += 2) {
         quad_iter(std::integral_constant<int, 0>{});
-        if (q + 1 < nq) quad_iter(std::integral_constant<int, kWsBufBytes>{});
+        if (q + 1 < B.nq) quad_iter(std::integral_constant<int, kWsBufBytes>{});
+    }
+}
+
+// CFG 0: 768 threads = 4 memory waves + 8 compute waves of 4 units (<= 168 VGPRs); CFG 1: 1024 threads = 4 memory waves + 8 compute
+// waves of 3 units + 4 of 2 units (<= 128 VGPRs; waves w, w + 4, w + 8, w + 12 share a SIMD, so every SIMD computes 3 + 3 + 2 units)
+template <int METHOD, int VT, typename TO, bool PRE, int CFG>
+__global__ void __launch_bounds__(CFG == 0 ? 768 : 1024)
+k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords, TO *__restrict__ out, int C, int H, int W,
+         int X, int Y, int Z, int nby, int nbz, int bricks_per_sample, int total_blocks, int nv, Gate gate)
+{
+    // nv <= VT views are real (3 views run the 4-view kernel): the others have no camera, no window and no part in the aggregate --
+    // their samples read kAbsentSample from a slot of the zero region (softmax, max) or plain zeros (sum, mean)
+    if (gated_off(gate)) return;
+    static_assert(sizeof(TO) == 4, "fp32 volumes (16-bit volumes: k_fwd_brick)");
+    static_assert(!PRE || METHOD == AGG_SOFTMAX, "only the softmax reads a prescaled copy");
+    constexpr int NMW = kWsMemWaves, NCW = CFG == 0 ? 8 : 12;
+    extern __shared__ __align__(16) unsigned char smem[];
+    FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + kWsLdsBytes);
+    const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
+
+    // XCD-aware order as in k_fwd_brick (speed only): blocks i, i + 8, ... share an XCD under round-robin dispatch; all eight XCDs work
+    // on the same sample, each on a compact tile of brick columns (all z)
+    const int nbx = bricks_per_sample / (nby * nbz);
+    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
+    const int tw = (nbx + tiles_x - 1) / tiles_x, th = (nby + tiles_y - 1) / tiles_y;
+    const int share = tw * th * nbz;
+    const int bid = (int)blockIdx.x, xcd = bid & 7, j = bid >> 3;
+    const int b = j / share, r = j % share;
+    const int kz = r % nbz, cy = (r / nbz) % th, cx = r / (nbz * th);
+    const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
+    if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
+    WsBrick<TO> B;
+    B.N = (long long)X * Y * Z;
+    B.nq = C >> 2; B.H = H; B.W = W; B.X = X; B.Y = Y; B.Z = Z; B.nv = nv; B.b = b; B.kx = kx; B.ky = ky; B.kz = kz;
+    B.obase = out + (long long)b * C * B.N;
+    B.fk = featK + (long long)b * nv * B.nq * (H * W);
+    B.chan_bytes = (unsigned)(B.N * sizeof(TO));
+    B.lds_base = (unsigned)(size_t)(lds_void_t *)smem;
+
+    if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
+    if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
+    __syncthreads();
+
+    if (wave < NMW) {
+        __syncthreads();                                                         // the compute waves' boxes are complete
+        ws_memory_role<VT, TO, NMW>(smem, sh, B, wave, lane);
+        return;
+    }
+    const int cw = wave - NMW, ctid = tid - NMW * 64;
+    if constexpr (CFG == 0) {
+        ws_compute_role<METHOD, VT, TO, PRE, 4>(smem, sh, B, coords, cw * 4, lane, ctid, NCW * 64);
+    } else {
+        if (cw < 8) ws_compute_role<METHOD, VT, TO, PRE, 3>(smem, sh, B, coords, cw * 3, lane, ctid, NCW * 64);
+        else ws_compute_role<METHOD, VT, TO, PRE, 2>(smem, sh, B, coords, 24 + (cw - 8) * 2, lane, ctid, NCW * 64);
     }
 }
 
@@ -494,13 +595,15 @@ hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const 
     constexpr int VT = 4;
     const int nbx = (p.X + 7) / 8, nby = (p.Y + 7) / 8, nbz = (p.Z + kBZ - 1) / kBZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
-    const size_t lds = (size_t)kWsLdsBytes + sizeof(FwdShared<VT>);
-    auto kern = k_fwd_ws<METHOD, VT, float, PRE>;
+    static_assert(sizeof(FwdShared<VT>) <= 1024 && kWsSyncOff + 16 <= 160 * 1024, "LDS layout");
+    const size_t lds = (size_t)kWsSyncOff + 16;
+    constexpr int CFG = MVHMR_WS_CFG;
+    auto kern = k_fwd_ws<METHOD, VT, float, PRE, CFG>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
     const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;   // tile work items x 8 XCDs x samples
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kWsThreads), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, total, p.V,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG == 0 ? 768 : 1024), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, total, p.V,
                        make_gate(p, true));
     return hipGetLastError();
 }

@@ -179,7 +179,11 @@ bool brick_fwd_supported(const Problem &p)
 #endif
 bool brick_fwd_ws_shape(const Problem &p) { return !MVHMR_NO_WS && brick_fwd_supported(p) && brick_fwd_ws_shape_impl(p); }
 // its softmax reads a copy of the features multiplied by log2(e): the layout pass in front of it scales (Problem::feat_log2e)
+#ifdef MVHMR_EXP_OLDPRE
+bool brick_fwd_prescales(const Problem &p) { return brick_fwd_supported(p) && brick_fwd_ws_shape_impl(p) && p.method == AGG_SOFTMAX; }
+#else
 bool brick_fwd_prescales(const Problem &p) { return brick_fwd_ws_shape(p) && p.method == AGG_SOFTMAX; }
+#endif
 
 GateGeom brick_fwd_gate_geom(const Problem &p)
 {
@@ -187,7 +191,7 @@ GateGeom brick_fwd_gate_geom(const Problem &p)
         GateGeom g;
         g.bx = 8; g.by = 8; g.bz = kBZ; g.column_major = 1; g.parity_rows = 1; g.view_group = 0;
         g.cap_slots = kWsCapSlots;
-        g.max_chunks = kWsChunks * kWsMemWaves;
+        g.max_chunks = kWsChunkTotal;
         return g;
     }
     const int nt = brick_fwd_grouped(p) ? 1024 : fwd_threads(p.V);

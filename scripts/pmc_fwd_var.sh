@@ -9,7 +9,7 @@ pass() {
   name=$1; shift
   out=$R/gpurun_out/pmc_${var}_$name
   timeout -k 10 200 rocprofv3 --pmc "$@" --output-format csv -d $out -- python3 $R/scripts/exp/bench_variant.py $var --steps 2 --warmup 1 --no-cpu-baseline --no-check --no-backward $EXTRA > $out.log 2>&1 || return 1
-  python3 $R/scripts/pmc_summary.py $out k_fwd_brick >> $R/gpurun_out/pmc_${var}.txt
+  python3 $R/scripts/pmc_summary.py $out ${KERN:-k_fwd} >> $R/gpurun_out/pmc_${var}.txt
 }
 rm -f $R/gpurun_out/pmc_${var}.txt
 for p in $passes; do

@@ -1685,3 +1685,105 @@ def test_layout_pass_takes_misaligned_feature_pointers(gpu):
         for o, g in outs[1:]:
             assert torch.equal(o, outs[0][0])
             record_err("misaligned features (%s): gradient vs the aligned run" % str(dt), float((g.float() - outs[0][1].float()).abs().max()), 1e-3 * float(outs[0][1].float().abs().max()))
+
+
+# ------------------------------------------------------------------------------------ round 5: the wave-specialised forward (k_fwd_ws)
+def _ws_desc(f, c, mode, layout=_capi.LAYOUT_BVCHW, variant="brick"):
+    return aggregation._make_desc(f, tuple(c.shape[1:4]), _capi.AGG[mode], torch.float32, layout, _capi.VARIANT[variant])
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=16, V=4, C=8, H=48, W=48, vol=(32, 32, 32)),       # 256 bricks: whole bricks, two quads (both window buffers, the odd-quad offset)
+    dict(B=9, V=4, C=12, H=40, W=56, vol=(20, 36, 44)),       # ragged in x, y and z (z % 4 == 0), odd number of quads, non-square maps
+    dict(B=9, V=3, C=8, H=40, W=40, vol=(20, 36, 44)),        # three views on the four-view kernel: the fourth absent
+    dict(B=4, V=4, C=4, H=400, W=400, vol=(64, 64, 32)),      # huge maps: no brick's windows fit -> the compute waves' global-memory path
+    dict(B=5, V=4, C=8, H=96, W=96, vol=(64, 64, 32)),        # the north star's geometry (1.45 px per voxel): rounded and unrounded windows
+])
+@pytest.mark.parametrize("mode", MODES)
+def test_wave_specialised_forward_vs_oracle(shape, mode, gpu):
+    """launches of >= 256 bricks with 3 / 4 views and an fp32 volume run k_fwd_ws (brick_fwd_ws.h): memory waves + compute waves,
+    results through LDS; its softmax reads a log2(e)-prescaled copy (mvhmr_preferred_layout says so)"""
+    feats, proj, coords = _ring_problem(seed=31 + MODES.index(mode), **shape)
+    f, p, c = torch.from_numpy(feats).to(gpu), torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    d = _ws_desc(f, c, mode)
+    lay = _capi.lib().mvhmr_preferred_layout(ctypes.byref(d))
+    assert lay == (_capi.LAYOUT_QUAD_LOG2E if mode == "softmax" else _capi.LAYOUT_QUAD)    # i.e. this shape runs k_fwd_ws
+    out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick")
+    ref = cport.forward(feats, proj, coords, mode)
+    name = "ws fwd %s V%d C%d %dx%d vol%s" % (mode, shape["V"], shape["C"], shape["H"], shape["W"], shape["vol"])
+    record_err(name, _err(out.cpu().numpy(), ref), TOL)
+    assert torch.equal(out, aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick"))   # deterministic
+    gat = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="gather")
+    # sum / mean / max: the same samples in the same order; softmax: exp2 of prescaled samples against exp of the samples
+    record_err(name + " vs gather", float((out - gat).abs().max()), 4e-6 if mode == "softmax" else 1e-6)
+    auto = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="auto")        # through the device-side gate
+    record_err(name + " auto", _err(auto.cpu().numpy(), ref), TOL)
+
+
+def test_wave_specialised_softmax_over_the_whole_float_range(gpu):
+    """as test_brick_softmax_over_the_whole_float_range, at a shape k_fwd_ws takes: exponentials relative to view 0 on prescaled
+    samples, overflow test per channel pair (denominators below 2^60), the max form as the fallback"""
+    feats, proj, coords = _ring_problem(B=4, V=4, C=8, H=48, W=48, vol=(64, 64, 32), seed=78)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    for scale in (100.0, 1e4, 1e30):
+        f = np.ascontiguousarray(feats * np.float32(scale))
+        f[:, :, 1] = feats[:, :, 1]
+        f[:, 0, 2] -= np.float32(0.9 * scale)
+        f[:, 0, 3] += np.float32(0.9 * scale)
+        with np.errstate(all="ignore"):
+            ref = cport.forward(f, proj, coords, "softmax")
+        assert np.isfinite(ref).all()
+        out = aggregation.unprojection(torch.from_numpy(f).to(gpu), p, c, aggregation_method="softmax", variant="brick").cpu().numpy()
+        assert np.isfinite(out).all()
+        big = [0, 2, 3, 4, 5, 6, 7]
+        record_err("ws softmax range x%g, O(1) channel" % scale, _err(out[:, 1], ref[:, 1]), TOL)
+        record_err("ws softmax range x%g, relative to max |ref|" % scale, _err(out[:, big], ref[:, big]) / float(np.abs(ref[:, big]).max()), 8e-6)
+    fn = feats.copy()
+    fn[0, 0, 5, 20:28, 20:28] = np.nan
+    fn[0, 1, 6, 16:24, 16:24] = np.inf
+    out = aggregation.unprojection(torch.from_numpy(fn).to(gpu), p, c, aggregation_method="softmax", variant="brick").cpu().numpy()
+    gat = aggregation.unprojection(torch.from_numpy(fn).to(gpu), p, c, aggregation_method="softmax", variant="gather").cpu().numpy()
+    assert np.array_equal(np.isfinite(out), np.isfinite(gat)) and (~np.isfinite(out)).any()
+    with np.errstate(all="ignore"):
+        ref = cport.forward(fn, proj, coords, "softmax")
+    fin = np.isfinite(ref) & np.isfinite(out)
+    record_err("ws softmax non-finite samples, finite part", _err(out[fin], ref[fin]), TOL)
+
+
+def test_prescaled_quad_layout_contract(gpu):
+    """MVHMR_LAYOUT_QUAD_LOG2E (ABI 4): produced by mvhmr_convert_features, accepted by exactly the forward that asks for it"""
+    feats, proj, coords = _ring_problem(B=16, V=4, C=8, H=48, W=48, vol=(32, 32, 32), seed=5)
+    f, p, c = torch.from_numpy(feats).to(gpu), torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    L, vp = _capi.lib(), ctypes.c_void_p
+    stream = vp(torch.cuda.current_stream(gpu).cuda_stream)
+    d = _ws_desc(f, c, "softmax")
+    assert L.mvhmr_preferred_layout(ctypes.byref(d)) == _capi.LAYOUT_QUAD_LOG2E
+    nb = L.mvhmr_feature_layout_bytes(ctypes.byref(d), _capi.LAYOUT_QUAD_LOG2E)
+    assert nb == L.mvhmr_feature_layout_bytes(ctypes.byref(d), _capi.LAYOUT_QUAD) > 0
+    q1 = torch.empty(nb // 4, device=gpu)
+    q0 = torch.empty(nb // 4, device=gpu)
+    _capi.check(L.mvhmr_convert_features(ctypes.byref(d), vp(f.data_ptr()), _capi.LAYOUT_QUAD_LOG2E, vp(q1.data_ptr()), stream))
+    _capi.check(L.mvhmr_convert_features(ctypes.byref(d), vp(f.data_ptr()), _capi.LAYOUT_QUAD, vp(q0.data_ptr()), stream))
+    assert torch.equal(q1, q0 * np.float32(1.4426950408889634))                              # one fp32 multiply per value
+    out = torch.empty(16, 8, 32, 32, 32, device=gpu)
+    dk = _capi.Desc.from_buffer_copy(d)
+    dk.feat_layout = _capi.LAYOUT_QUAD_LOG2E
+    assert L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(dk)) == 0
+    _capi.check(L.mvhmr_unproject_forward(ctypes.byref(dk), vp(q1.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(out.data_ptr()), vp(0), 0, stream))
+    assert torch.equal(out, aggregation.unprojection(f, p, c, variant="brick"))              # the planar route makes the same copy itself
+    # the unscaled copy through the same kernel family: within the two softmax forms' rounding
+    dk.feat_layout = _capi.LAYOUT_QUAD
+    out0 = torch.empty_like(out)
+    _capi.check(L.mvhmr_unproject_forward(ctypes.byref(dk), vp(q0.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(out0.data_ptr()), vp(0), 0, stream))
+    record_err("prescaled vs unscaled quad copy", float((out - out0).abs().max()), 4e-6)
+    # everything else refuses it: another aggregate, the gather variant, the backward
+    dk.feat_layout = _capi.LAYOUT_QUAD_LOG2E
+    for field, value in (("method", _capi.AGG["sum"]), ("variant", _capi.VARIANT["gather"])):
+        bad = _capi.Desc.from_buffer_copy(dk)
+        setattr(bad, field, value)
+        assert L.mvhmr_unproject_forward(ctypes.byref(bad), vp(q1.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(out.data_ptr()), vp(0), 0, stream) == _capi.ERR_UNSUPPORTED
+    assert L.mvhmr_unproject_backward_supported(ctypes.byref(dk)) == 0
+    g = torch.empty_like(f)
+    assert L.mvhmr_unproject_backward(ctypes.byref(dk), vp(out.data_ptr()), vp(q1.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(g.data_ptr()), vp(0), 0, stream) == _capi.ERR_UNSUPPORTED
+    small = _ws_desc(f[:2], c[:2], "softmax")                                                # 32 bricks: k_fwd_brick, unscaled
+    assert L.mvhmr_preferred_layout(ctypes.byref(small)) == _capi.LAYOUT_QUAD
