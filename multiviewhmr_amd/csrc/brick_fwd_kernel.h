@@ -30,22 +30,6 @@
 
 namespace mvhmr {
 
-// Timing-only ablations for scripts/exp (never defined in the product build): bit 0 conflict-free fake tap addresses, 1 no tap reads,
-// 2 no LDS-DMA, 3 no stores, 4 no transcendentals, 5 no transpose, 6 no per-quad barrier, 7 no aggregate, 8 no wait for the DMA,
-// 9 LDS-DMA without the m0 save / restore, 10 phase timers of a brick (s_memtime, summed over all waves: mvhmr_exp_fwd_timers_read),
-// 11 stores wrapped into the first 1 MiB of the volume (they stay in L2: no HBM writes), 12 LDS-DMA sources wrapped into 128 KiB
-// (L1 / L2 hits: no miss latency), 13 only every other LDS-DMA piece, 14 only two of the four channel stores
-#ifndef MVHMR_EXP
-#define MVHMR_EXP 0
-#endif
-constexpr int kExp = MVHMR_EXP;
-#if MVHMR_EXP & 1024
-__device__ unsigned long long g_exp_fwd_timers[8];
-#define EXP_FT(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define EXP_FT(i) do { } while (0)
-#endif
-
 // Window layout in LDS (MVHMR_FWD_LAY): 0 = plain column-major (slot = column * stride + row); 1 = the rows of a column split by
 // PARITY: slot = column * 2 hp + (row & 1) * hp + (row >> 1), window origin row even.  A bilinear footprint {y0, y0 + 1} has one row
 // of each parity, so read instruction "even row" / "odd row" of a view fetches, for z-neighbouring lanes (1.45 px apart at the north
@@ -70,16 +54,7 @@ __device__ unsigned long long g_exp_fwd_timers[8];
 #define MVHMR_FWD_MAP16 1          // the lane map of 16-bit volumes: 1 = z runs + pair exchange of channel pairs, 0 = round 3's stride-4 transpose
 #endif
 constexpr int kFwdLay = MVHMR_FWD_LAY, kFwdMapF32 = MVHMR_FWD_MAP, kFwdHp = MVHMR_FWD_HP;
-#ifndef MVHMR_FWD_PRIO
-#define MVHMR_FWD_PRIO 0           // experiment: s_setprio 3 around the stores (bit 0) / from the stores to behind the LDS-DMA site (bit 1)
-#endif
-#ifndef MVHMR_FWD_VADDR
-#define MVHMR_FWD_VADDR 0          // 1: tap addresses from VGPR operands (full-rate adds); measured, no gain (ablations section L)
-#endif
-#ifndef MVHMR_FWD_STAUX
-#define MVHMR_FWD_STAUX 18
-#endif
-constexpr int kStAux = MVHMR_FWD_STAUX;         // cache policy of the volume stores: nt | sc1 (plain 3.56 ms, sc0 3.55, sc1 3.54, nt 3.44, nt sc1 3.46: r04 ablations)
+constexpr int kStAux = 18;         // cache policy of the volume stores: nt | sc1 (plain 3.56 ms, sc0 3.55, sc1 3.54, nt 3.44, nt sc1 3.46: r04 ablations)
 
 // map 0: lane = 32 g + 16 h + 4 a + b  ->  column h of the wave's two (x-adjacent) columns, z = 16 g + 4 b + a
 // map 1: lane = 32 h + l5; lane quads of l5 -> z quads {0, 16, 20, 4, 24, 8, 12, 28} (+ lane & 3): the LDS pass groups are z runs
@@ -123,62 +98,11 @@ __device__ __forceinline__ void stride4_transpose(float (&r)[4], int lane)
     }
 }
 
-// aggregate<> behind the timing-only ablations (kExp == 0: exactly aggregate<>)
-template <int METHOD, int VT>
-__device__ __forceinline__ float fwd_aggregate(const float (&s)[VT])
-{
-    if constexpr (kExp & 128) {
-        float r = s[0];
-#pragma unroll
-        for (int v = 1; v < VT; ++v) r += s[v];
-        return r;
-    } else if constexpr ((kExp & 16) && METHOD == AGG_SOFTMAX && VT == 4) {
-        const float m = vmax(vmax3(s[0], s[1], s[2]), s[3]);
-        const float nm = -m * 1.4426950408889634f;
-        float den = 0.f, num = 0.f;
-#pragma unroll
-        for (int v = 0; v < VT; ++v) {
-            float e = fmaf(s[v], 1.4426950408889634f, nm);
-            e = fmaf(e, 0.5f, 1.f);                                              // stands in for v_exp_f32
-            den += e;
-            num = fmaf(e, s[v], num);
-        }
-        return num * fmaf(den, 0.25f, 1.f);                                      // stands in for v_rcp_f32
-    } else {
-        return aggregate<METHOD, VT>(s);
-    }
-}
-
-// aggregate2<> behind the timing-only ablations
+// the aggregate of a channel pair; mean over nv < VT real views: the sum of the real ones (the absent ones sample zeros) rescaled
 template <int METHOD, int VT>
 __device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const float (&sb)[VT], float &ra, float &rb, float mean_fix)
 {
-    if constexpr (kExp & (16 | 128)) {
-        ra = fwd_aggregate<METHOD, VT>(sa);
-        rb = fwd_aggregate<METHOD, VT>(sb);
-#ifdef MVHMR_EXP_OLDPRE
-    } else if constexpr (METHOD == AGG_SOFTMAX && VT == 4) {
-        // timing experiment: the prescaled softmax of brick_fwd_ws.h in k_fwd_brick
-        float ta[VT], tb[VT];
-#pragma unroll
-        for (int v = 1; v < VT; ++v) { ta[v] = sa[v] - sa[0]; tb[v] = sb[v] - sb[0]; }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int v = 1; v < VT; ++v) { ta[v] = __builtin_amdgcn_exp2f(ta[v]); tb[v] = __builtin_amdgcn_exp2f(tb[v]); }
-        __builtin_amdgcn_sched_barrier(0);
-        float da = 1.f, db = 1.f, na = sa[0], nb = sb[0];
-#pragma unroll
-        for (int v = 1; v < VT; ++v) { da += ta[v]; na = fmaf(ta[v], sa[v], na); db += tb[v]; nb = fmaf(tb[v], sb[v], nb); }
-        __builtin_amdgcn_sched_barrier(0);
-        float ia = __builtin_amdgcn_rcpf(da), ib = __builtin_amdgcn_rcpf(db);
-        __builtin_amdgcn_sched_barrier(0);
-        ia *= 0.6931471805599453f; ib *= 0.6931471805599453f;
-        ra = na * ia; rb = nb * ib;
-        if (__builtin_amdgcn_ballot_w64(!(da + db < 1.152921504606847e18f)) != 0) { ra = aggregate<METHOD, VT>(sa); rb = aggregate<METHOD, VT>(sb); }
-#endif
-    } else {
-        aggregate2<METHOD, VT>(sa, sb, ra, rb);
-    }
+    aggregate2<METHOD, VT>(sa, sb, ra, rb);
     if constexpr (METHOD == AGG_MEAN) { ra *= mean_fix; rb *= mean_fix; }          // VT / nv (1 when every view is real: exact)
 }
 
@@ -216,9 +140,6 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     // their samples read kAbsentSample from a slot of the zero region (softmax weight exp(-FLT_MAX - m) = 0, never the maximum) or
     // plain zeros (sum; mean, which is rescaled by VT / nv)
     if (gated_off(gate)) return;
-#if MVHMR_EXP & 1024
-    unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
-#endif
     constexpr int BY = NT / 128, NW = NT / 64, BXK = kBX * NVOX;
     constexpr int MAP = sizeof(TO) == 4 ? kFwdMapF32 : MVHMR_FWD_MAP16, LAY = kFwdLay;
     constexpr int SPJ = MAP == 1 ? (sizeof(TO) == 4 ? 4 : 2) : 1;                // store instructions per job
@@ -296,9 +217,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             }
         }
     }
-    EXP_FT(0);                                                                   // projections staged, tap records, wave boxes
     __syncthreads();
-    EXP_FT(1);                                                                   // barrier: block boxes complete
 
     // ---- window per view (block-uniform): origin, column stride (odd) in slots, first slot; views packed back to back
     // LAY 1: origin row even, hp half-rows per parity, column stride 2 hp; hp rounded to 8 by policy kFwdHp
@@ -379,7 +298,6 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                         w00[u][v] = w10[u][v]; w01[u][v] = w11[u][v]; w10[u][v] = t0; w11[u][v] = t1;
                     }
                 }
-                if constexpr (kExp & 1) a0[u][v] = kZeroBytes + (lane + 64 * v + 256 * u) * 16;
                 if (kAbsentReads && v >= nv) {                                   // wave-uniform: the absent view's one "tap"
                     a0[u][v] = kAbsentSlot * 16;
                     if constexpr (LAY != 0) a1[u][v] = kAbsentSlot * 16;
@@ -413,7 +331,6 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 gx = gx < 0 ? 0 : (gx > W - 1 ? W - 1 : gx);                     // image: clamp -- those slots only meet zero weights
                 gy = gy < 0 ? 0 : (gy > H - 1 ? H - 1 : gy);
                 g_off[rr] = (unsigned)((v * nqv) * HW + gx * H + gy) * 16u;
-                if constexpr (kExp & 4096) g_off[rr] &= 0x1FFF0u;
                 l_dst[rr] = uniform(kZeroBytes + (s0 + (jj << 6)) * 16) + (int)(unsigned)(size_t)(lds_void_t *)smem;
                 ++n_c;
             }
@@ -425,7 +342,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         auto dma = [&](int roff) __attribute__((always_inline)) {
 #pragma unroll
             for (int rr = 0; rr < MC; ++rr)
-                if (rr < n_c && !(kExp & 4) && !((kExp & 8192) && (rr & 1))) glds16_m0(src_n, g_off[rr], (unsigned)(l_dst[rr] + roff));
+                if (rr < n_c) glds16_m0(src_n, g_off[rr], (unsigned)(l_dst[rr] + roff));
             src_n += HW;
         };
 
@@ -444,7 +361,6 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 st_off[u] = inside[u] ? (vox[u] - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes : 0x80000000u;
             } else if constexpr (MAP == 1) {
                 st_off[u] = inside[u] ? vox[u] * OSZ : 0x80000000u;               // bit 31: beyond num_records, the store is dropped
-                if constexpr (kExp & 2048) st_off[u] &= 0x3FFFFu;
             } else {
                 static_assert(MAP == 1, "the stride-4 transpose map writes four z per lane: whole bricks only");
                 const int z0 = ((lane >> 5) << 4) + ((lane & 3) << 2);
@@ -452,7 +368,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             }
         }
         auto make_rs = [&](TO *base) __attribute__((always_inline)) {
-            return __builtin_amdgcn_make_buffer_rsrc((kExp & 2048) ? out : base, 0, (int)(4u * chan_bytes), 0x00020000);
+            return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)(4u * chan_bytes), 0x00020000);
         };
         auto store_quad = [&](const __amdgpu_buffer_rsrc_t rs, int u, float (&res)[4]) __attribute__((always_inline)) {
             if constexpr (MAP == 1 && OSZ == 2) {
@@ -463,25 +379,15 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 // even lane: (own channel i at z, partner's channel i at z+1); odd lane: (partner's channel 2+i at z-1, own at z)
                 const unsigned d0 = odd ? pack2<TO>(g0, res[2]) : pack2<TO>(res[0], g0);
                 const unsigned d1 = odd ? pack2<TO>(g1, res[3]) : pack2<TO>(res[1], g1);
-                if constexpr (kExp & 8) {
-                    asm volatile("" :: "v"(d0), "v"(d1), "s"(rs));
-                } else {
-                    __builtin_amdgcn_raw_buffer_store_b32(d0, rs, (int)st_off[u], 0, kStAux);
-                    __builtin_amdgcn_raw_buffer_store_b32(d1, rs, (int)st_off[u], (int)chan_bytes, kStAux);
-                }
+                __builtin_amdgcn_raw_buffer_store_b32(d0, rs, (int)st_off[u], 0, kStAux);
+                __builtin_amdgcn_raw_buffer_store_b32(d1, rs, (int)st_off[u], (int)chan_bytes, kStAux);
             } else if constexpr (MAP == 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if constexpr (kExp & 16384) { if (i >= 2) { asm volatile("" :: "v"(res[i]), "s"(rs)); continue; } }
-                    if constexpr (kExp & 8) asm volatile("" :: "v"(res[i]), "s"(rs));
-                    else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rs, (int)st_off[u],
-                                                               (kExp & 2048) ? i * 0x40000 : (int)(i * chan_bytes), (kExp & 2048) ? 0 : kStAux);
-                }
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, res[i]), rs, (int)st_off[u], (int)(i * chan_bytes), kStAux);
             } else {
-                if constexpr (!(kExp & 32)) stride4_transpose(res, lane);
-                if constexpr (kExp & 8) {
-                    asm volatile("" :: "v"(res[0]), "v"(res[1]), "v"(res[2]), "v"(res[3]), "s"(rs));
-                } else if constexpr (OSZ == 4) {
+                stride4_transpose(res, lane);
+                if constexpr (OSZ == 4) {
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
                     const u32x4 d = {__builtin_bit_cast(unsigned, res[0]), __builtin_bit_cast(unsigned, res[1]),
                                      __builtin_bit_cast(unsigned, res[2]), __builtin_bit_cast(unsigned, res[3])};
@@ -497,30 +403,15 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         // ---- taps: two register sets of 4 x b128 (LAY 0: nw, ne, sw, se; LAY 1: even row x0 / x0+1, odd row x0 / x0+1), used
         // alternately by consecutive views
         f32x4 T[2][4];
-        // (MVHMR_FWD_VADDR = 1, softmax kernels only: the others have no registers to spare) the ring offset and the column strides
-        // held in VGPRs for the tap addresses: a v_add_u32 with an SGPR operand issues at half rate on gfx950
-        // (profiles/r03_microbench.txt), and a job has 32 of them.  Priced 25 ns per wave and job less; measured: nothing.
-        constexpr bool kVaddr = MVHMR_FWD_VADDR && METHOD == AGG_SOFTMAX;
-        int ws16v[VT];
-#pragma unroll
-        for (int v = 0; v < VT; ++v) {
-            if constexpr (kVaddr) asm volatile("v_mov_b32 %0, %1" : "=v"(ws16v[v]) : "s"(uniform(ws16[v])));
-            else ws16v[v] = ws16[v];
-        }
+        // (the ring offset and the column strides as VGPR operands of the address adds -- full-rate instead of half-rate v_add_u32 --
+        // were measured at nothing: profiles/r04_fwd_ablations.txt section L)
         auto read_view = [&](int roff, int u, int v, int set) __attribute__((always_inline)) {
-            const int base = a0[u][v] + roff, far = base + ws16v[v];
-            if constexpr (kExp & 2) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(T[set][t].v[i]) : "v"(base), "v"(far));
-                return;
-            }
+            const int base = a0[u][v] + roff, far = base + ws16[v];
             if constexpr (LAY == 0) {
                 T[set][0] = lds_tap(smem, base); T[set][2] = lds_tap(smem, base + 16);
                 T[set][1] = lds_tap(smem, far); T[set][3] = lds_tap(smem, far + 16);
             } else {
-                const int base1 = a1[u][v] + roff, far1 = base1 + ws16v[v];
+                const int base1 = a1[u][v] + roff, far1 = base1 + ws16[v];
                 T[set][0] = lds_tap(smem, base); T[set][2] = lds_tap(smem, base1);
                 T[set][1] = lds_tap(smem, far); T[set][3] = lds_tap(smem, far1);
             }
@@ -537,7 +428,6 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         dma(0);                                                                  // quad 0 -> buffer 0
         if (nb == 3 && nq > 1) dma(r1);                                          // quad 1 -> buffer 1
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the zero regions are written
-        EXP_FT(2);                                                               // windows, addresses, chunk table, first DMA issued
         __amdgpu_buffer_rsrc_t rs_cur = make_rs(obase), rs_prev = rs_cur;
         TO *oq_cur = obase;
         const long long qstride = 4 * N;                                         // elements between the channel planes of consecutive quads
@@ -555,7 +445,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
         constexpr int DMA_U = 0, DMA_V = (VT + 1) / 2 < VT ? (VT + 1) / 2 : VT - 1;
         auto quad_iter = [&](int q, auto par_tag) __attribute__((always_inline)) {
             constexpr int PAR = decltype(par_tag)::value;
-            if constexpr (!(kExp & 256)) {
+            {
                 // three buffers: store groups behind the DMA site in its own quad + everything of the next quad
                 constexpr int K2 = NVOX * SPJ, K3 = (NVOX - DMA_U - (DMA_V >= (VT + 1) / 2 ? 1 : 0)) * SPJ + NVOX * SPJ;
                 static_assert(K3 + MC <= 63, "vmcnt is a 6-bit field");
@@ -563,14 +453,9 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 else if (nb == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(K2) : "memory");
                 else wait_vmcnt_ladder<K3, MC, MC>(n_c);
             }
-            if constexpr (!(kExp & 64)) bare_barrier();
-#if MVHMR_EXP & 1024
-            if (q == 0) EXP_FT(3);                                               // window 0 landed + barrier
-#endif
+            bare_barrier();
             if (nb == 2 && q + 1 < nq) dma(r1);
-            int r0v;                                                             // this quad's ring offset for the tap addresses
-            if constexpr (kVaddr) asm volatile("v_mov_b32 %0, %1" : "=v"(r0v) : "s"(r0));
-            else r0v = r0;
+            const int r0v = r0;                                                  // this quad's ring offset for the tap addresses
 #pragma unroll
             for (int u = 0; u < NVOX; ++u) {
                 // this job's samples go to sq / sp alternately; the previous job's are aggregated in two halves between the folds
@@ -586,10 +471,8 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 for (int v = 0; v < VT; ++v) {
                     if (v == (VT + 1) / 2) {
                         fwd_aggregate2<METHOD, VT>(prev[2], prev[3], res[2], res[3], mean_fix);
-                        if constexpr (MVHMR_FWD_PRIO & 1) __builtin_amdgcn_s_setprio(3);  // experiment: memory instructions ahead of the other waves' arithmetic
                         if (u > 0) store_quad(rs_cur, u - 1, res);
                         else if (q > 0) store_quad(rs_prev, NVOX - 1, res);
-                        if constexpr (MVHMR_FWD_PRIO == 1) __builtin_amdgcn_s_setprio(0);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -599,11 +482,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     if (v + 2 < VT) read_view(r0v, u, v + 2, v & 1);
-                    if (u == DMA_U && v == DMA_V && nb == 3 && q + 2 < nq) {
-                        if constexpr (MVHMR_FWD_PRIO & 2) __builtin_amdgcn_s_setprio(3);
-                        dma(r2);
-                    }
-                    if constexpr (MVHMR_FWD_PRIO & 2) { if (v == DMA_V) __builtin_amdgcn_s_setprio(0); }
+                    if (u == DMA_U && v == DMA_V && nb == 3 && q + 2 < nq) dma(r2);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -630,13 +509,6 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
             else fwd_aggregate2<METHOD, VT>(sq[c], sq[c + 1], res[c], res[c + 1], mean_fix);
         }
         store_quad(rs_prev, NVOX - 1, res);
-        EXP_FT(4);                                                               // the quad loop
-#if MVHMR_EXP & 1024
-        if (lane == 0) {
-            for (int i = 0; i < 5; ++i) atomicAdd(&g_exp_fwd_timers[i], t_acc[i]);
-            atomicAdd(&g_exp_fwd_timers[6], 1ull);
-        }
-#endif
     } else {
         // ---- windows do not fit the LDS pool: sample straight from global memory (clamped taps, zero weights outside)
 #pragma unroll
@@ -736,9 +608,7 @@ hipError_t launch_fwd_method(const void *featK_, const float *proj, const Coords
         if (p.feat_log2e) return hipErrorNotSupported;
         return launch_fwd_ws_instance<METHOD, false>(featK, proj, coords, (float *)out, p, s);
     }
-#ifndef MVHMR_EXP_OLDPRE
     if (p.feat_log2e) return hipErrorNotSupported;                               // only the wave-specialised softmax reads a prescaled copy
-#endif
 #define MVHMR_FWD_CASE(NVIEWS, NTHR, NV)                                                                                                 \
     if (brick_view_slots(p.V) == NVIEWS && nvox == NV)                                                                                                   \
         return p.out_f16    ? launch_fwd_instance<METHOD, NVIEWS, NTHR, __half, NV>(featK, proj, coords, (__half *)out, p, s)            \

@@ -44,10 +44,6 @@ constexpr int kWsSyncOff = kWsLdsBytes + 1024;                       // one LDS 
 constexpr int kWsChunkTotal = 64;                                    // LDS-DMA pieces per quad (64 x 64 slots >= cap), dealt to the memory waves
 static_assert(kWsCapSlots % 64 == 0 && kWsCapSlots <= kWsChunkTotal * 64, "window pool / chunk table");
 constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-#ifndef MVHMR_WS_EXP
-#define MVHMR_WS_EXP 0                                                            // timing-only (scripts/exp): 1 no LDS-DMA / stores, 2 no arithmetic, 4 no barrier B, 8 no stores, 16 no LDS-DMA
-#endif
-constexpr int kWsExp = MVHMR_WS_EXP;
 
 // window geometry of a brick (block-uniform; the same arithmetic in both roles and in k_brick_gate)
 template <int VT>
@@ -234,7 +230,7 @@ __device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdSha
     auto dma = [&](int boff) __attribute__((always_inline)) {
 #pragma unroll
         for (int rr = 0; rr < MC; ++rr)
-            if (rr < n_m && !(kWsExp & (1 | 16))) glds16_m0(src_n, go[rr], B.lds_base + (unsigned)(boff + kZeroBytes + (wave + rr * NMW) * 1024));
+            if (rr < n_m) glds16_m0(src_n, go[rr], B.lds_base + (unsigned)(boff + kZeroBytes + (wave + rr * NMW) * 1024));
         src_n += HW;
     };
     // ---- stores: instruction j = wave + NMW k (k < NS) writes channel j >> 3, brick row y = j & 7: lane = (x, z quad) reads
@@ -270,23 +266,11 @@ __device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdSha
             if (q + 1 < B.nq) dma(((q + 1) & 1) * kWsBufBytes);                  // every wave has passed A(q): the other buffer is free
         }
         if (q > 0) {
-            __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(B.obase + (long long)((q - 1) * 4) * B.N, 0, (int)(4u * B.chan_bytes), 0x00020000);
-            if constexpr (kWsExp & 32) {
-                // timing only: the (brick, quad)'s 32 KiB of results as ONE contiguous region of the output buffer
-                const long long region = ((long long)blockIdx.x * B.nq + (q - 1)) * 8192;   // north-star shape: the grid has exactly one block per brick
-                rs = __builtin_amdgcn_make_buffer_rsrc(B.obase - (long long)B.b * (B.nq * 4) * B.N + region, 0, 32768, 0x00020000);
-#pragma unroll
-                for (int k = 0; k < NS; ++k) {
-                    const u32x4 d = {__builtin_bit_cast(unsigned, res[k].x), __builtin_bit_cast(unsigned, res[k].y),
-                                     __builtin_bit_cast(unsigned, res[k].z), __builtin_bit_cast(unsigned, res[k].w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(d, rs, lane * 16, (wave + NMW * k) * 1024, kStAux);
-                }
-                continue;
-            }
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(B.obase + (long long)((q - 1) * 4) * B.N, 0, (int)(4u * B.chan_bytes), 0x00020000);
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
                 const int jj = wave + NMW * k, ys = jj & 7, ch = jj >> 3;
-                if (B.ky * 8 + ys < B.Y && !(kWsExp & (1 | 8))) {
+                if (B.ky * 8 + ys < B.Y) {
                     const u32x4 d = {__builtin_bit_cast(unsigned, res[k].x), __builtin_bit_cast(unsigned, res[k].y),
                                      __builtin_bit_cast(unsigned, res[k].z), __builtin_bit_cast(unsigned, res[k].w)};
                     __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)voff, (int)(ys * ystep + ch * B.chan_bytes), kStAux);
@@ -455,7 +439,6 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
         return seen;
     };
     auto wait_r_free = [&](int seen) __attribute__((always_inline)) {
-        if constexpr (kWsExp & 4) return;
         asm volatile("s_waitcnt lgkmcnt(15)" : "+v"(seen) : : "memory");
         while (uniform(seen) < r_need) {
             __builtin_amdgcn_s_sleep(1);
@@ -463,13 +446,6 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
         }
     };
     auto quad_iter = [&](auto boff) __attribute__((always_inline)) {
-        if constexpr (kWsExp & 2) {
-            wait_r_free(read_r_counter());
-            write_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
-            r_need += 64 * kWsMemWaves;
-            lds_barrier();
-            return;
-        }
         auto job = [&](auto utag) __attribute__((always_inline)) {
             constexpr int u = decltype(utag)::value;
             auto &cur = (u & 1) ? sp : sq;

@@ -179,11 +179,7 @@ bool brick_fwd_supported(const Problem &p)
 #endif
 bool brick_fwd_ws_shape(const Problem &p) { return !MVHMR_NO_WS && brick_fwd_supported(p) && brick_fwd_ws_shape_impl(p); }
 // its softmax reads a copy of the features multiplied by log2(e): the layout pass in front of it scales (Problem::feat_log2e)
-#ifdef MVHMR_EXP_OLDPRE
-bool brick_fwd_prescales(const Problem &p) { return brick_fwd_supported(p) && brick_fwd_ws_shape_impl(p) && p.method == AGG_SOFTMAX; }
-#else
 bool brick_fwd_prescales(const Problem &p) { return brick_fwd_ws_shape(p) && p.method == AGG_SOFTMAX; }
-#endif
 
 GateGeom brick_fwd_gate_geom(const Problem &p)
 {
