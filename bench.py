@@ -60,7 +60,48 @@ def parse():
     ap.add_argument("--cpu-sample-batch", type=int, default=8, help="samples of the workload timed on the host (about 15 s)")
     ap.add_argument("--train-step", action="store_true", help="time one aggregator training step (fwd + bwd + grad all-reduce)")
     ap.add_argument("--in-channels", type=int, default=None, help="--train-step: input channels of the 1x1 conv (default: --channels)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="one rank, one GPU: initialise the 'nccl' (= RCCL) backend with world size 1 and run the path's collective on the device "
+                         "(proves init_process_group, the IPC-mode pin and the flat-buffer all-reduce load and run on this pool; no scaling number)")
     return ap.parse_args()
+
+
+def rccl_selftest(a):
+    """The RCCL leg of this file on ONE GPU: the 8-GPU driver run must not be that code's first execution.
+    World size 1 measures no scaling; it proves that backend 'nccl' initialises on this pool (HSA_ENABLE_IPC_MODE_LEGACY=0), that the
+    collectives of the N > 1 path (barrier, the MAX reduce of the elapsed time, the flat fp32 gradient all-reduce) execute on the
+    device, and that sharding.allreduce_aggregator_grads leaves a one-rank module's gradients as they were."""
+    import socket
+    import torch.distributed as dist
+    from multiviewhmr_amd import sharding
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    t0 = time.perf_counter()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=dev)
+    t_init = time.perf_counter() - t0
+    dist.barrier()
+    t = torch.tensor([1.25], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)                       # the reduce bench.py applies to the elapsed time
+    assert float(t.item()) == 1.25
+    C = a.channels
+    rccl = time_grad_allreduce(C * C + C, dev, True, 1)
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(C, C, 1).to(dev)                        # process_feature (models/aggregation.py:108-110)
+    conv(torch.randn(2, C, 8, 8, device=dev)).square().mean().backward()
+    before = [p.grad.clone() for p in conv.parameters()]
+    n = sharding.allreduce_aggregator_grads(conv)
+    torch.cuda.synchronize()
+    same = all(torch.equal(b, p.grad) for b, p in zip(before, conv.parameters()))
+    assert n == C * C + C and same, "one-rank all-reduce changed the gradients"
+    print(json.dumps({"rccl_selftest": {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "init_s": round(t_init, 2),
+                                        "allreduce": rccl, "flat_grad_elements": n, "grads_unchanged": same,
+                                        "note": "one rank: no scaling number; proves the RCCL leg loads and runs on this pool"}}), flush=True)
+    dist.destroy_process_group()
 
 
 def spawn_ranks(n):
@@ -241,6 +282,8 @@ def train_step_bench(a, rank, world, dev, use_rccl):
 # ------------------------------------------------------------------------------------------- main
 def main():
     a = parse()
+    if a.rccl_selftest:
+        return rccl_selftest(a)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

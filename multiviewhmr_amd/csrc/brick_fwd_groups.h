@@ -22,7 +22,6 @@ __device__ __attribute__((noinline)) void fwd_groups_slow(const float4 *fk, TO *
                                                           long long N, unsigned vox, int nq, int nqv, int H, int W, int nv)
 {
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
-    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
     const int HW = H * W;
     float c0, c1, c2;
     voxel_xyz(coords, b, N, vox, c0, c1, c2);
@@ -53,8 +52,9 @@ __device__ __attribute__((noinline)) void fwd_groups_slow(const float4 *fk, TO *
         TO *oq = obase + (long long)(q * 4) * N;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float r = aggregate<METHOD, VT>(s[i]);
-            if constexpr (METHOD == AGG_MEAN) r *= mean_fix;
+            float r;
+            if constexpr (METHOD == AGG_MEAN) r = __fdiv_rn(aggregate<AGG_SUM, VT>(s[i]), (float)nv);
+            else r = aggregate<METHOD, VT>(s[i]);
             (oq + i * N)[vox] = from_f32<TO>(r);
         }
     }
@@ -163,7 +163,6 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     TO *const obase = out + (long long)b * C * N + (long long)(q0 * 4) * N;
     const float4 *const fk = featK + (long long)b * nv * nqv * HW + (long long)q0 * HW;
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
-    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
 
     if (fits) {
         for (int i = tid; i < kZeroSlots * 2; i += NT) {
@@ -239,7 +238,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
         const unsigned chan_bytes = (unsigned)(N * OSZ);
         const int z0 = ((lane >> 5) << 4) + ((lane & 3) << 2);
         static_assert(MAP == 1, "the stride-4 transpose map writes four z per lane: whole bricks only");
-        const unsigned st_off = !inside ? 0x80000000u                                // bit 31: beyond num_records, the stores are dropped
+        const unsigned st_off = !inside ? kDropOffset                                // beyond num_records: the stores are dropped
                               : MAP == 1 ? (OSZ == 4 ? vox * OSZ : (vox - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes)
                                          : (vox - (unsigned)zin + (unsigned)z0) * OSZ + (unsigned)((lane >> 2) & 3) * chan_bytes;
         auto store_quad = [&](int q, float (&res)[4]) __attribute__((always_inline)) {
@@ -317,8 +316,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
             float res[4];
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
-                aggregate2<METHOD, VT>(s[i], s[i + 1], res[i], res[i + 1]);
-                if constexpr (METHOD == AGG_MEAN) { res[i] *= mean_fix; res[i + 1] *= mean_fix; }
+                fwd_aggregate2<METHOD, VT>(s[i], s[i + 1], res[i], res[i + 1], (float)nv);
             }
             store_quad(q, res);
         }

@@ -54,6 +54,7 @@ namespace mvhmr {
 #define MVHMR_FWD_MAP16 1          // the lane map of 16-bit volumes: 1 = z runs + pair exchange of channel pairs, 0 = round 3's stride-4 transpose
 #endif
 constexpr int kFwdLay = MVHMR_FWD_LAY, kFwdMapF32 = MVHMR_FWD_MAP, kFwdHp = MVHMR_FWD_HP;
+constexpr unsigned kDropOffset = 0xFFFFFFF0u;   // a buffer offset past every num_records this library builds (the range check ignores soffset): that lane's store is dropped
 constexpr int kStAux = 18;         // cache policy of the volume stores: nt | sc1 (plain 3.56 ms, sc0 3.55, sc1 3.54, nt 3.44, nt sc1 3.46: r04 ablations)
 
 // map 0: lane = 32 g + 16 h + 4 a + b  ->  column h of the wave's two (x-adjacent) columns, z = 16 g + 4 b + a
@@ -98,12 +99,17 @@ __device__ __forceinline__ void stride4_transpose(float (&r)[4], int lane)
     }
 }
 
-// the aggregate of a channel pair; mean over nv < VT real views: the sum of the real ones (the absent ones sample zeros) rescaled
+// the aggregate of a channel pair; mean over nv <= VT real views: the sum (the absent ones sample zeros) divided by nv -- the reference's
+// volume.mean(0) bit for bit, as the gather kernels compute it
 template <int METHOD, int VT>
-__device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const float (&sb)[VT], float &ra, float &rb, float mean_fix)
+__device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const float (&sb)[VT], float &ra, float &rb, float nvf)
 {
-    aggregate2<METHOD, VT>(sa, sb, ra, rb);
-    if constexpr (METHOD == AGG_MEAN) { ra *= mean_fix; rb *= mean_fix; }          // VT / nv (1 when every view is real: exact)
+    if constexpr (METHOD == AGG_MEAN) {
+        ra = __fdiv_rn(aggregate<AGG_SUM, VT>(sa), nvf);
+        rb = __fdiv_rn(aggregate<AGG_SUM, VT>(sb), nvf);
+    } else {
+        aggregate2<METHOD, VT>(sa, sb, ra, rb);
+    }
 }
 
 // s_waitcnt vmcnt(K + n) with an immediate for a wave-uniform n in 0 .. MAXI, tried from the likely end (a wave owns most of its MAXI
@@ -266,7 +272,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     TO *const obase = out + (long long)b * C * N + (long long)(q0 * 4) * N;
     const float4 *const fk = featK + (long long)b * nv * nqv * HW + (long long)q0 * HW;
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;    // absent views sample kAbsentSample (else zeros)
-    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
+    const float mean_fix = (float)nv;                                             // the mean's divisor: the real views
 
     if (fits) {
         for (int i = tid; i < kZeroSlots * nb; i += NT) {
@@ -358,9 +364,9 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 // 16-bit volume: lanes 2m / 2m+1 (z, z+1 of one column) exchange channel pairs; the even lane writes (z, z+1) of
                 // channels 0 / 1 as one dword each, the odd lane those of channels 2 / 3: 64-B runs per channel and column
                 // (Z even: a pair is inside or outside the volume as a whole)
-                st_off[u] = inside[u] ? (vox[u] - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes : 0x80000000u;
+                st_off[u] = inside[u] ? (vox[u] - (unsigned)(lane & 1)) * OSZ + (unsigned)(lane & 1) * 2u * chan_bytes : kDropOffset;
             } else if constexpr (MAP == 1) {
-                st_off[u] = inside[u] ? vox[u] * OSZ : 0x80000000u;               // bit 31: beyond num_records, the store is dropped
+                st_off[u] = inside[u] ? vox[u] * OSZ : kDropOffset;               // beyond num_records (<= 2^32 - 16): the store is dropped
             } else {
                 static_assert(MAP == 1, "the stride-4 transpose map writes four z per lane: whole bricks only");
                 const int z0 = ((lane >> 5) << 4) + ((lane & 3) << 2);
@@ -540,8 +546,9 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
                 if (inside[u]) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float r = aggregate<METHOD, VT>(s[i]);
-                        if constexpr (METHOD == AGG_MEAN) r *= mean_fix;
+                        float r;
+                        if constexpr (METHOD == AGG_MEAN) r = __fdiv_rn(aggregate<AGG_SUM, VT>(s[i]), mean_fix);
+                        else r = aggregate<METHOD, VT>(s[i]);
                         (oq + i * N)[vox[u]] = from_f32<TO>(r);
                     }
                 }

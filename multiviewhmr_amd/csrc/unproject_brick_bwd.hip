@@ -95,7 +95,6 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
 {
     const int HW = H * W;
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
-    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
     float w00[VT], w01[VT], w10[VT], w11[VT];
     int o00[VT], o01[VT], o10[VT], o11[VT];
 #pragma unroll
@@ -125,10 +124,10 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float g = to_f32<TO>(gobase[(long long)(q * 4 + i) * N + vox]);
-            if constexpr (METHOD == AGG_MEAN) g *= mean_fix;
+            const float g = to_f32<TO>(gobase[(long long)(q * 4 + i) * N + vox]);
             float ds[VT];
-            aggregate_grad<METHOD, VT>(s[i], g, ds);
+            if constexpr (METHOD == AGG_MEAN) aggregate_grad<AGG_SUM, VT>(s[i], __fdiv_rn(g, (float)nv), ds);   // g / (real views), as autograd of mean(0)
+            else aggregate_grad<METHOD, VT>(s[i], g, ds);
 #pragma unroll
             for (int v = 0; v < VT; ++v) {
                 if (v >= nv) continue;                                           // absent view: nothing to receive
@@ -244,7 +243,6 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     const float4 *const fk = featK + (long long)b * nv * nq * HW;
     float *const gk = gradK + (long long)b * nv * nq * HW * 4;
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
-    const float mean_fix = nv < VT ? (float)VT / (float)nv : 1.f;
     const TO *const gobase = grad_out + (long long)b * C * N;
     const unsigned chan_bytes = (unsigned)(N * 4);
     const unsigned voxb = inside ? vox * 4u : 0x80000000u;                       // beyond num_records: the load returns 0
@@ -424,7 +422,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         // ds of channel i of quad q from its samples and gn[i]; the block-wide max |ds| is published for the quad's scale
         auto jacobian_to = [&](int aset, int i, float (&dsi)[VT]) __attribute__((always_inline)) {
             const float gi = grad_of(gn[i]);
-            aggregate_grad<METHOD, VT>(s[i], METHOD == AGG_MEAN ? gi * mean_fix : gi, dsi);
+            if constexpr (METHOD == AGG_MEAN) aggregate_grad<AGG_SUM, VT>(s[i], __fdiv_rn(gi, (float)nv), dsi);   // g / (real views), as autograd of mean(0)
+            else aggregate_grad<METHOD, VT>(s[i], gi, dsi);
             if (nv < VT) {                                                       // wave-uniform, as is every test below
 #pragma unroll
                 for (int v = 1; v < VT; ++v)                                     // a move, not a product: 0 * fma(g, -FLT_MAX, c) can be NaN.  (As

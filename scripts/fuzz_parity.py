@@ -30,6 +30,19 @@ def run(seed=1, cases=60, big=False, dtype="f32", verbose=True):
             X, Y, Z = int(rng.choice([8, 16])), int(rng.choice([8, 12, 16])), int(rng.choice([32, 64]))
             C = int(rng.choice([4, 8]))
         B = int(rng.integers(1, 3))
+        # r05: the shapes above all lie below AUTO's brick threshold (B * X * Y * Z >= 196 608 voxels), so `auto` only ever ran
+        # the gather kernels.  One case per seed is batched up to the threshold (the device-side gate then decides), and one to >= 256
+        # bricks with z % 4 == 0, where 3 / 4 views with an fp32 volume run the wave-specialised forward (brick_fwd_ws.h)
+        if case == 1:
+            B = -(-196608 // (X * Y * Z))
+            C = min(C, 8)
+        if case == 2:
+            Z = (Z + 3) & ~3
+            V = int(rng.choice([3, 4]))
+            B = -(-256 // (-(-X // 8) * -(-Y // 8) * -(-Z // 32)))
+            C = min(C, 8)
+        if B > 40:                                                                # keep the oracle in seconds
+            H, W = min(H, 40), min(W, 40)
         side = float(rng.uniform(600.0, 3000.0)); centre = rng.uniform(-300.0, 300.0, 3)
         theta = float(rng.uniform(0, 2 * np.pi)); radius = float(rng.uniform(1200.0, 6000.0)); focal = float(rng.uniform(700.0, 1800.0))
         feats = rng.standard_normal((B, V, C, H, W), dtype=np.float32) * float(rng.choice([0.3, 1.0, 4.0, 12.0]))
@@ -81,7 +94,22 @@ def run(seed=1, cases=60, big=False, dtype="f32", verbose=True):
                 got = f.grad.float().cpu().numpy().astype(np.float64)
                 bad = np.abs(got - gref) > (bound(gref) + gulp * float(np.abs(gref).max()))
                 mass = np.abs(got.sum(axis=(1, 3, 4)) - gref.astype(np.float64).sum(axis=(1, 3, 4))).max()
-                if bad.mean() < 2e-4 and mass <= 64 * (bound(gref) + gulp * float(np.abs(gref).max())):
+                # r05: ... and every wrong pixel must lie in the 2 x 2 footprint of a voxel whose two largest samples really
+                # tie (to a few ulps of the sample, half-precision features: of their rounding) in one of the tied views -- an indexing or
+                # arg-max bug that moves footprints elsewhere conserves the mass just as well and must not pass
+                from oracle import unproject_np
+                smp, tables = unproject_np.per_view_samples(feats, proj, coords)          # (B, V, C, N)
+                top = np.sort(smp, axis=1)
+                tol = (8 * 2.0 ** -23 + 4 * ulp) * np.maximum(np.abs(top[:, -1]), 1e-30)
+                tie = (top[:, -1] - top[:, -2]) <= tol                                    # (B, C, N)
+                allowed = np.zeros(bad.shape, bool).reshape(B, V, C, H * W)
+                for (b_, v_), (off, w, ok) in tables.items():
+                    tv = tie[b_] & (smp[b_, v_] >= top[b_, -1] - tol[b_])                 # (C, N): view v_ is one of the tied ones
+                    for k in range(4):
+                        for c_ in range(C):
+                            allowed[b_, v_, c_, off[k][tv[c_] & ok[k]]] = True
+                explained = not (bad & ~allowed.reshape(bad.shape)).any()
+                if explained and bad.mean() < 2e-4 and mass <= 64 * (bound(gref) + gulp * float(np.abs(gref).max())):
                     e2 = 1.0
             n += 1
             if max(e1, e2) > worst:

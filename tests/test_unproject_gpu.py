@@ -1787,3 +1787,25 @@ def test_prescaled_quad_layout_contract(gpu):
     assert L.mvhmr_unproject_backward(ctypes.byref(dk), vp(out.data_ptr()), vp(q1.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(g.data_ptr()), vp(0), 0, stream) == _capi.ERR_UNSUPPORTED
     small = _ws_desc(f[:2], c[:2], "softmax")                                                # 32 bricks: k_fwd_brick, unscaled
     assert L.mvhmr_preferred_layout(ctypes.byref(small)) == _capi.LAYOUT_QUAD
+
+
+@pytest.mark.parametrize("views", (3, 6))
+def test_mean_over_absent_views_is_one_division_by_the_real_views(views, gpu):
+    """3 / 6 views run the 4- / 8-view brick kernels with the missing views absent.  Their mean is sum / V (one IEEE division, the
+    reference's volume.mean(0)) -- not sum / 4 * (4 / 3).  Checked on the brick kernels' own sum: their samples may differ
+    from the gather kernels' in the last bit (the parity-split windows add the four bilinear products in another order)"""
+    feats, proj, coords = _ring_problem(B=2, V=views, C=8, H=24, W=24, vol=(8, 8, 32), seed=300 + views)
+    f, p, c = torch.from_numpy(feats).to(gpu), torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    brick = aggregation.unprojection(f, p, c, aggregation_method="mean", variant="brick")
+    total = aggregation.unprojection(f, p, c, aggregation_method="sum", variant="brick")
+    # one correctly rounded fp32 division (numpy: torch's GPU division by a scalar multiplies by the reciprocal)
+    assert np.array_equal(brick.cpu().numpy(), total.cpu().numpy() / np.float32(views))
+    gather = aggregation.unprojection(f, p, c, aggregation_method="mean", variant="gather")
+    record_err("mean V%d brick vs gather" % views, float((brick - gather).abs().max()), 1e-6)
+    ref = cport.forward(feats, proj, coords, "mean")
+    record_err("mean V%d brick fwd" % views, _err(brick.cpu().numpy(), ref), TOL)
+    fb = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    go = np.random.default_rng(9).standard_normal(ref.shape, dtype=np.float32)
+    aggregation.unprojection(fb, p, c, aggregation_method="mean", variant="brick").backward(torch.from_numpy(go).to(gpu))
+    gref = cport.backward(go, feats, proj, coords, "mean")
+    record_err("mean V%d brick bwd" % views, _err(fb.grad.cpu().numpy(), gref), _bound(gref))
