@@ -33,6 +33,16 @@ __device__ __forceinline__ void bare_barrier()
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
+// f(integral_constant<int, I>) for I = FROM .. TO - 1, unrolled at compile time (indices that must reach immediate operands)
+template <int FROM, int TO, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (FROM < TO) {
+        f(std::integral_constant<int, FROM>{});
+        static_for<FROM + 1, TO>(f);
+    }
+}
+
 // LDS-DMA of 16 B per lane: lane l's bytes land at lds_dst + 16*l (lds_dst wave-uniform), read from base + voff[l].
 // Written as inline asm on purpose: hipcc tracks the builtin form as a pending LDS write and puts s_waitcnt vmcnt(0)
 // in front of every later ds_read, which drains the whole ring and the output stores each quad.  The asm form is

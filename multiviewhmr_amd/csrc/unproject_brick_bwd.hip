@@ -24,67 +24,26 @@
 
 namespace mvhmr {
 
-// Timing-only ablations for scripts/exp (never defined in the product build; bit 9 no tap reads, 10 no window DMA, 11 no float -> int conversion in the adds): bit 0 no flush atomics, 1 plain stores instead of the
-// flush atomics, 2 no LDS adds, 3 no barriers in the quad loop (only the waits stay), 4 / 5 waves 8-15 / odd waves start the quad loop ~3 us late
-#ifndef MVHMR_EXP_BWD
-#define MVHMR_EXP_BWD 0
-#endif
-// Round-4 structure experiments, all measured at 12.6-12.9 ms like the shipped form (profiles/r04_fwd_ablations.txt, section K) and left
-// in as build options (scripts/exp):
-//   MVHMR_BWD_PSETS=2     two gradient plane sets for the 8 x 8 x 16 bricks: quad q accumulates into set q & 1 while quad q - 1 is flushed
-//                         from the other one -- one barrier per quad, the flush's atomics issued between the adds (after
-//                         MVHMR_BWD_FLUSH_AT channels); costs window capacity (2 368 instead of 3 264 slots)
-//   MVHMR_BWD_FLIP=1      waves 4-7 and 12-15 (two of the four on every SIMD) run each channel as Jacobian -> adds, the others adds -> Jacobian
-//   MVHMR_BWD_PLANE_PAD=16  planes 16 banks apart (kZeroSlots + cap is a multiple of 64: the flush's 4 planes x 16 slots meet in 16 banks)
-#ifndef MVHMR_BWD_ASYNC_G
-#define MVHMR_BWD_ASYNC_G 0           // 1: grad_out loads of the quad loop as inline asm (see load_g_async): measured, no gain
-#endif
-#ifndef MVHMR_BWD_PSETS
-#define MVHMR_BWD_PSETS 1
-#endif
-#ifndef MVHMR_BWD_FLIP
-#define MVHMR_BWD_FLIP 0
-#endif
-#ifndef MVHMR_BWD_FLUSH_AT
-#define MVHMR_BWD_FLUSH_AT 2
-#endif
-constexpr int kExpB = MVHMR_EXP_BWD;
 // s_waitcnt vmcnt(0) as the builtin: the compiler's own wait-count bookkeeping sees it (an asm wait it does not, and then guards the
 // grad_out registers with waits of its own in the middle of the add phase)
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); asm volatile("" ::: "memory"); }
 typedef int int4v __attribute__((ext_vector_type(4)));                 // a buffer descriptor as four SGPRs (inline asm operand)
-// bit 6: phase timers of the quad loop (s_memtime, summed over all waves): mvhmr_exp_timers_read() -- experiment builds only
-#if MVHMR_EXP_BWD & 64
-__device__ unsigned long long g_exp_timers[8];
-#define EXP_T(i) do { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); t_acc[i] += t_now - t_prev; t_prev = t_now; } while (0)
-#else
-#define EXP_T(i) do { } while (0)
-#endif
-
 // LDS: [ feature buffer 0 | feature buffer 1 | 4 gradient planes | BrickShared ]
 //   feature buffer = kZeroBytes of zeros + cap 16-B slots (as in the forward)
 //   gradient plane = (kZeroSlots + cap) floats; the first kZeroSlots only ever receive +0 (samples that are identically zero)
 constexpr int kBwdLdsBytes = 160 * 1024 - 1024;
-// experiment bit 7: 2 / 4 views as 512-thread blocks of 8 x 4 x 16 voxels with half the pool each -- two independent blocks per CU
-constexpr int bwd_lds_bytes(int nt, int vt) { return ((kExpB & 128) && nt == 512 && vt <= 4) ? 80 * 1024 - 1024 : kBwdLdsBytes; }
 // brick shapes: 4 x (threads / 128) x 32 voxels (128-B grad_out runs per wave half), or 8 x 8 x 16 for 1024 threads (64-B runs, but a
 // third fewer window pixels per voxel at ~1.3 px per voxel: the flush and the window DMA shrink with it)
 constexpr int bwd_brick_x(int bz) { return bz == 32 ? kBX : 8; }
 // two feature windows in LDS (the next quad's is prefetched) -- except for the 4 x 4 x 32 bricks of 8 views, which need the room for
 // their windows (mean 3 300, max 4 600 slots at the configs[3] geometry; 8 x 4 x 16: 2 450 / 3 072) and keep one
 constexpr int bwd_feature_buffers(int nt, int bz) { return (nt >= 1024 || bz == 16) ? 2 : 1; }
-#ifndef MVHMR_BWD_PLANE_PAD
-#define MVHMR_BWD_PLANE_PAD 0
-#endif
-constexpr int kPlanePad = MVHMR_BWD_PLANE_PAD;   // words between the end of a gradient plane and the next one
-// gradient plane sets: 1; MVHMR_BWD_PSETS=2 gives the 8 x 8 x 16 bricks of 2 / 4 views (smallest windows per voxel, <= 2 048 slots at the
-// north star) a second one
-constexpr int bwd_plane_sets(int nt, int bz) { return (MVHMR_BWD_PSETS == 2 && nt >= 1024 && bz == 16) ? 2 : 1; }
-// slots per window set: NBUF * (kZeroBytes + 16 cap) + PSETS * 4 planes * 4 B * (kZeroSlots + cap) <= the pool
-constexpr int bwd_cap_slots(int nt, int bz, int vt = 8)
+// (round 4 measured, at no gain: a second gradient plane set with the flush of quad q - 1 among the adds of quad q, planes 16 banks apart,
+// half of the waves running Jacobian -> adds, two 512-thread blocks per CU -- profiles/r04_fwd_ablations.txt section K)
+// slots per window set: NBUF * (kZeroBytes + 16 cap) + 4 planes * 4 B * (kZeroSlots + cap) <= the pool
+constexpr int bwd_cap_slots(int nt, int bz)
 {
-    return ((bwd_lds_bytes(nt, vt) - bwd_feature_buffers(nt, bz) * kZeroBytes - bwd_plane_sets(nt, bz) * 16 * (kZeroSlots + kPlanePad)) /
-            (16 * bwd_feature_buffers(nt, bz) + 16 * bwd_plane_sets(nt, bz))) & ~63;
+    return ((kBwdLdsBytes - bwd_feature_buffers(nt, bz) * kZeroBytes - 16 * kZeroSlots) / (16 * bwd_feature_buffers(nt, bz) + 16)) & ~63;
 }
 constexpr int kAuxCmax = 12;       // BrickShared::aux word of the tap multiplicity
 
@@ -141,7 +100,7 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
 }
 
 template <int METHOD, int VT, int NT, typename TO, int BZ>
-__global__ void __launch_bounds__(NT, ((kExpB & 128) && NT == 512 && VT <= 4) ? 4 : 1)
+__global__ void __launch_bounds__(NT)
 k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, const float *__restrict__ proj,
             const Coords coords, float *__restrict__ gradK, int C, int H, int W, int X, int Y, int Z, int nby,
             int nbz, int bricks_per_sample, int lds_bytes, int total_blocks, int nv, Gate gate)
@@ -153,8 +112,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     constexpr int BX = bwd_brick_x(BZ), BY = NT / (BZ * BX), NW = NT / 64, CW = 64 / BZ;
     constexpr int MC = brick_chunks_per_wave(NT);
     constexpr int NBUF = bwd_feature_buffers(NT, BZ);                               // feature windows in LDS: 2 (next quad prefetched) or 1
-    constexpr int PSETS = bwd_plane_sets(NT, BZ);                                   // gradient plane sets: 2 = flush of quad q - 1 under the adds of quad q
-    constexpr int ASETS = PSETS == 2 ? 3 : 2;                                       // max-|ds| words: one set per quad in flight
+    constexpr int ASETS = 2;                                                        // max-|ds| words: one set per quad in flight
     extern __shared__ __align__(16) unsigned char smem[];
     BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_bytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
@@ -233,11 +191,9 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     }
     // capacity (bwd_cap_slots): compile-time, so that the plane and
     // buffer strides fold into the immediate offsets of the ds_ instructions (run-time strides cost 32 address registers)
-    constexpr int cap = bwd_cap_slots(NT, BZ, VT);
+    constexpr int cap = bwd_cap_slots(NT, BZ);
     constexpr int buf_bytes = kZeroBytes + cap * 16;
-    // + kPlanePad: kZeroSlots + cap is a multiple of 64, i.e. of the bank count -- the flush reads 16 slots of each of the 4 planes per
-    // instruction, which then met in 16 banks four deep; 16 words of padding put the planes 16 banks apart
-    constexpr int plane_floats = kZeroSlots + cap + kPlanePad;
+    constexpr int plane_floats = kZeroSlots + cap;
     int *const iplanes = reinterpret_cast<int *>(smem + NBUF * buf_bytes);
     const bool fits = used <= cap && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots;
     const float4 *const fk = featK + (long long)b * nv * nq * HW;
@@ -252,7 +208,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             const float z = (kAbsentReads && nv < VT && i % kZeroSlots == kAbsentSlot) ? kAbsentSample : 0.f;
             *reinterpret_cast<float4 *>(smem + (i / kZeroSlots) * buf_bytes + (i % kZeroSlots) * 16) = make_float4(z, z, z, z);
         }
-        for (int i = tid; i < PSETS * 4 * plane_floats; i += NT) iplanes[i] = 0;
+        for (int i = tid; i < 4 * plane_floats; i += NT) iplanes[i] = 0;
         if (tid < 13) sh->aux[tid] = 0;
 
         const unsigned plane0 = (unsigned)(size_t)(lds_void_t *)smem + (unsigned)(NBUF * buf_bytes);   // LDS byte address of gradient plane 0
@@ -303,7 +259,6 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         }
         const unsigned lds_base = (unsigned)(size_t)(lds_void_t *)smem;
         auto dma = [&](int q) {
-            if constexpr (kExpB & 1024) return;                                  // timing only: no window DMA
             const float4 *src = fk + (long long)q * HW;
             const int boff = (q & (NBUF - 1)) * buf_bytes;
 #pragma unroll
@@ -312,7 +267,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         };
 
         // grad_out of this voxel's 4 channels (128-B runs per channel across the wave), one quad ahead
-        float gn[4], gnn[4];                                                     // gnn: two quads ahead (PSETS == 2 only)
+        float gn[4];
         auto load_g_to = [&](int q, float (&gn)[4]) __attribute__((always_inline)) {
             if constexpr (sizeof(TO) == 4) {
                 const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<TO *>(gobase) + (long long)(q * 4) * N, 0, (int)(4u * chan_bytes), 0x00020000);
@@ -328,30 +283,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             }
         };
         auto load_g = [&](int q) __attribute__((always_inline)) { load_g_to(q, gn); };
-        // The same loads for the quad loop, as inline asm: OUTSIDE the compiler's wait-count bookkeeping.  The compiler cannot see the
-        // hand-counted wait that ends an iteration (nor the LDS-DMA requests and flush atomics, which are asm too), so for loads it knows
-        // of it guards the first use of every gn[i] in the NEXT iteration with s_waitcnt vmcnt(3 - i) -- counted without the window
-        // requests issued in between, i.e. a wait for those requests in the middle of the add phase.  Built and measured
-        // (MVHMR_BWD_ASYNC_G=1): no difference (fp32 13.06 vs 13.03 ms, fp16 12.87 vs 12.86), so the builtin loads stay.  graw is
-        // written by the load and read only by take_g() behind the hand-counted wait; such a build must not spill VGPRs.
-        float graw[4];
-        auto load_g_async = [&](int q) __attribute__((always_inline)) {
-            if constexpr (sizeof(TO) == 4) {
-                const unsigned long long bits = (unsigned long long)(size_t)(gobase + (long long)(q * 4) * N);
-                const int4v desc = {uniform((int)(unsigned)bits), uniform((int)((unsigned)(bits >> 32) & 0xffffu)), (int)(4u * chan_bytes), 0x00020000};
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    asm volatile("buffer_load_dword %0, %1, %2, %3 offen" : "=v"(graw[i]) : "v"(voxb), "s"(desc), "s"((int)(i * chan_bytes)) : "memory");
-            } else {
-                const TO *gp = gobase + (long long)(q * 4) * N + vox;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("global_load_ushort %0, %1, off" : "=v"(graw[i]) : "v"(gp + (long long)i * N) : "memory");
-            }
-        };
-        auto take_g = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(gn[i]) : "v"(graw[i]));
-        };
+        // (the same loads as inline asm outside the compiler's wait-count bookkeeping -- no s_waitcnt vmcnt(3 - i) in front of each channel's
+        // Jacobian -- were measured at no difference in round 4: fp32 13.06 vs 13.03 ms)
         auto grad_of = [&](float held) __attribute__((always_inline)) {          // the value load_g_to left in gn[i]
             if constexpr (sizeof(TO) == 4) return held;
             // (a lane past the volume's edge keeps the gradient of the edge voxel it is clamped to: its weights are zero, so it adds nothing,
@@ -405,12 +338,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 __builtin_amdgcn_sched_barrier(0);
                 const int base = a0[v] + boff, row1 = base + ws16[v];
                 f32x4 ta, tb, tc, td;
-                if constexpr (kExpB & 512) {                                     // timing only: no tap reads
-                    const float z = __builtin_bit_cast(float, base);
-                    ta.v[0] = ta.v[1] = ta.v[2] = ta.v[3] = z; tb = ta; tc = ta; td = ta;
-                } else {
-                    ta = lds_tap(smem, base); tb = lds_tap(smem, base + 16); tc = lds_tap(smem, row1); td = lds_tap(smem, row1 + 16);
-                }
+                ta = lds_tap(smem, base); tb = lds_tap(smem, base + 16); tc = lds_tap(smem, row1); td = lds_tap(smem, row1 + 16);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     s[i][v] = bilerp(ta.v[i], tb.v[i], tc.v[i], td.v[i], w00[v], w01[v], w10[v], w11[v]);
@@ -419,11 +347,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             }
             __builtin_amdgcn_sched_barrier(0);
         };
-        // ds of channel i of quad q from its samples and gn[i]; the block-wide max |ds| is published for the quad's scale
-        auto jacobian_to = [&](int aset, int i, float (&dsi)[VT]) __attribute__((always_inline)) {
-            const float gi = grad_of(gn[i]);
-            if constexpr (METHOD == AGG_MEAN) aggregate_grad<AGG_SUM, VT>(s[i], __fdiv_rn(gi, (float)nv), dsi);   // g / (real views), as autograd of mean(0)
-            else aggregate_grad<METHOD, VT>(s[i], gi, dsi);
+        // absent views receive nothing; the block-wide max |ds| of the channel is published for the quad's fixed-point scale
+        auto publish_max = [&](int aset, int i, float (&dsi)[VT]) __attribute__((always_inline)) {
             if (nv < VT) {                                                       // wave-uniform, as is every test below
 #pragma unroll
                 for (int v = 1; v < VT; ++v)                                     // a move, not a product: 0 * fma(g, -FLT_MAX, c) can be NaN.  (As
@@ -444,11 +369,14 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // one scale per channel of the quad: wave max -> lane 63 -> ds_max into the block's word
             lds_max_from_lane63(aux_base + (unsigned)((aset * 4 + i) * 4), wave_max_to_last_row(big));
         };
+        // ds of channel i of quad q from its samples and gn[i]
+        auto jacobian_to = [&](int aset, int i, float (&dsi)[VT]) __attribute__((always_inline)) {
+            const float gi = grad_of(gn[i]);
+            if constexpr (METHOD == AGG_MEAN) aggregate_grad<AGG_SUM, VT>(s[i], __fdiv_rn(gi, (float)nv), dsi);   // g / (real views), as autograd of mean(0)
+            else aggregate_grad<METHOD, VT>(s[i], gi, dsi);
+            publish_max(aset, i, dsi);
+        };
         auto jacobian1 = [&](int aset, int i) __attribute__((always_inline)) { jacobian_to(aset, i, ds[i]); };
-        // MVHMR_BWD_FLIP: half of the waves (two of the four on every SIMD) run each channel as Jacobian -> adds, the others as adds ->
-        // Jacobian.  (Idea: a wave whose adds wait for a slot in the LDS queue cannot issue its arithmetic, so with all 16 waves in step the
-        // VALU would idle through the adds and the LDS through the Jacobians.  Measured: no difference.)
-        const bool flip = MVHMR_BWD_FLIP && ((wave >> 2) & 1);
         if (NBUF == 2 && nq > 1) dma(1);
         resample(0);
         if (NBUF == 1 && nq > 1) { lds_barrier(); dma(1); }                      // single buffer: every wave has sampled window 0
@@ -456,17 +384,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         for (int i = 0; i < 4; ++i) jacobian1(0, i);
         if (nq > 1) load_g(1);
         int aset = 0;                                                            // aux set of quad q (q % ASETS)
-        float inv_prev = 0.f;                                                    // PSETS == 2: 1 / scale and poison flag of quad q - 1, flushed during quad q
-        bool pois_prev = false;
         wait_vm0();                                                              // window 1 has landed
         lds_barrier();
-        if constexpr (kExpB & 48) {
-            const bool late = (kExpB & 16) ? wave >= NW / 2 : (wave & 1);
-            if (late) for (int i = 0; i < 100; ++i) __builtin_amdgcn_s_sleep(1);   // ~64 cycles each
-        }
-#if MVHMR_EXP_BWD & 64
-        unsigned long long t_acc[6] = {0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
-#endif
 #pragma nounroll
         for (int q = 0; q < nq; ++q) {
             // LDS float atomics run at ~190 cycles per wave instruction on gfx950, integer ones at ~4-6, so the window is
@@ -477,7 +396,6 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // The LDS pipe is in order: the window reads of quad q+1 go ahead of this quad's 64 adds per lane, whose
             // service time then hides under the Jacobian of quad q+1 (VALU only).
             if (q + 1 < nq) resample(q + 1);
-            EXP_T(0);                                                            // resample issued (+ loop top)
             // scales: integer arithmetic on wave-uniform values, kept on the scalar unit (the asm operands below are SGPRs) -- as float
             // selects the compiler built them with ~27 half-rate VALU instructions per quad
             float scale[4];
@@ -500,7 +418,6 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             if (q + 2 < nq) {
                 if (NBUF == 1) lds_barrier();                                    // single buffer: every wave has sampled window q+1
                 dma(q + 2);                                                      // into the buffer quad q (or q+1) was sampled from
-                if constexpr (PSETS == 2) load_g_to(q + 2, gnn);                 // ahead of this iteration's flush atomics (in-order vmcnt)
             }
             const int aset_next = aset + 1 == ASETS ? 0 : aset + 1;
             // channel by channel: the 16 adds of quad q (fire and forget: the LDS unit retires ~14.5 lane-adds per clock, so a wave
@@ -514,41 +431,22 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 constexpr int i = decltype(i_tag)::value;
                 constexpr int off = i * plane_floats * 4;
                 static_assert(3 * plane_floats * 4 + 4 < 65536, "plane offsets must fit the ds_ immediate");
-                auto adds = [&]() __attribute__((always_inline)) {
+                // the channel's 4 VT adds of quad q (two VALU instructions + the ds_add_u32 each), then its Jacobian of quad q + 1, which
+                // overwrites ds[i].  (Round 5 interleaved the two -- one add per three or four Jacobian instructions, on the theory that a
+                // wave sitting in the add burst cannot issue arithmetic -- and measured nothing, 12.87 vs 12.88 ms on one box: with sixteen
+                // waves at different points of the channel the other waves' arithmetic already fills the burst.  The interleaved form is
+                // scripts/exp/patches/bwd_interleaved_adds.patch; profiles/r05_bwd_ablations.txt has the numbers.)
 #pragma unroll
-                    for (int v = 0; v < VT; ++v) {
-                        if (!(kExpB & 4)) {
-                            const float d = ds[i][v] * scale[i];
-                            if constexpr (kExpB & 2048) {                        // timing only: no conversion (one VALU instruction per add)
-                                lds_add_at<off>(ga4[v], __builtin_bit_cast(int, d * w00[v]));
-                                lds_add_at<off + 4>(ga4[v], __builtin_bit_cast(int, d * w01[v]));
-                                lds_add_at<off>(gb4[v], __builtin_bit_cast(int, d * w10[v]));
-                                lds_add_at<off + 4>(gb4[v], __builtin_bit_cast(int, d * w11[v]));
-                            } else {
-                            lds_add_at<off>(ga4[v], round_int(d * w00[v]));
-                            lds_add_at<off + 4>(ga4[v], round_int(d * w01[v]));
-                            lds_add_at<off>(gb4[v], round_int(d * w10[v]));
-                            lds_add_at<off + 4>(gb4[v], round_int(d * w11[v]));
-                            }
-                        }
-                    }
-                };
-                if (flip) {
-                    float dsn[VT];
-                    if (q + 1 < nq) jacobian_to(aset_next, i, dsn);
-                    __builtin_amdgcn_sched_barrier(0);
-                    adds();
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (q + 1 < nq) {
-#pragma unroll
-                        for (int v = 0; v < VT; ++v) ds[i][v] = dsn[v];
-                    }
-                } else {
-                    adds();
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (q + 1 < nq) jacobian1(aset_next, i);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int v = 0; v < VT; ++v) {
+                    const float d = ds[i][v] * scale[i];
+                    lds_add_at<off>(ga4[v], round_int(d * w00[v]));
+                    lds_add_at<off + 4>(ga4[v], round_int(d * w01[v]));
+                    lds_add_at<off>(gb4[v], round_int(d * w10[v]));
+                    lds_add_at<off + 4>(gb4[v], round_int(d * w11[v]));
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                if (q + 1 < nq) jacobian1(aset_next, i);
+                __builtin_amdgcn_sched_barrier(0);
             };
             // ---- flush: 16 window slots x 4 channels = 256 contiguous bytes of the accumulator per wave instruction.
             // A slot that is not a live pixel (padding, outside the image) carries bit 31 in its offset: beyond the buffer's
@@ -578,7 +476,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
             // flush of quad qf from its plane set (scaled back by inv: this lane's channel), planes left zero
             auto flush_quad = [&](int qf, float inv, bool pois) __attribute__((always_inline)) {
                 const int q_off = qf * HW * 16;                                  // wave-uniform byte offset of the quad (soffset)
-                int *const pset = iplanes + (PSETS == 2 ? (qf & 1) * 4 * plane_floats : 0);
+                int *const pset = iplanes;
                 auto flush = [&](auto masked_tag) __attribute__((always_inline)) {
                     constexpr bool MASKED = decltype(masked_tag)::value;
 #pragma unroll
@@ -597,9 +495,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                         for (int jj = 0; jj < 4; ++jj) {
                             const float val = (float)iv[jj] * inv;
                             const int voff = (int)(off[jj] + ch4);
-                            if constexpr (kExpB & 2) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, val), rgk, voff, q_off, 0);
-                            else if constexpr (kExpB & 1) asm volatile("" :: "v"(val), "v"(voff));
-                            else if constexpr (MASKED) {
+                            if constexpr (MASKED) {
                                 unsigned long long save;
                                 asm volatile("s_mov_b64 %[save], exec\n\t"
                                              "v_cmpx_ne_u32_e32 vcc, 0, %[iv]\n\t"
@@ -620,78 +516,19 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 };
                 if (pois) flush(std::false_type{}); else flush(std::true_type{});
             };
-            if constexpr (PSETS == 2 && MVHMR_BWD_FLUSH_AT == 0) { if (q > 0) flush_quad(q - 1, inv_prev, pois_prev); }
             adds_of_channel(std::integral_constant<int, 0>{});
-            if constexpr (PSETS == 2 && MVHMR_BWD_FLUSH_AT == 1) { if (q > 0) flush_quad(q - 1, inv_prev, pois_prev); }
             adds_of_channel(std::integral_constant<int, 1>{});
-            if constexpr (PSETS == 2 && MVHMR_BWD_FLUSH_AT == 2) { if (q > 0) flush_quad(q - 1, inv_prev, pois_prev); }
             adds_of_channel(std::integral_constant<int, 2>{});
-            if constexpr (PSETS == 2 && MVHMR_BWD_FLUSH_AT == 3) { if (q > 0) flush_quad(q - 1, inv_prev, pois_prev); }
             adds_of_channel(std::integral_constant<int, 3>{});
-            if constexpr (PSETS == 2 && MVHMR_BWD_FLUSH_AT == 4) { if (q > 0) flush_quad(q - 1, inv_prev, pois_prev); }
-            if constexpr (PSETS == 2) {
-                // ---- one barrier per quad: the adds of quad q went into set q & 1, the flush above emptied the other one
-#pragma unroll
-                for (int v = 0; v < VT; ++v) {                                   // the next quad's adds go to the other set
-                    const unsigned d = (unsigned)(4 * plane_floats * 4);
-                    ga4[v] = (q & 1) ? ga4[v] - d : ga4[v] + d;
-                    gb4[v] = (q & 1) ? gb4[v] - d : gb4[v] + d;
-                }
-                if (tid < 4 && q > 0) sh->aux[(aset == 0 ? ASETS - 1 : aset - 1) * 4 + tid] = 0;   // quad q-1's words: read a barrier ago, written again two from now
-                inv_prev = inv_ch; pois_prev = poisoned;
-                EXP_T(1);
-                // window q+2 and grad_out q+2 (requested before this iteration's atomics) have landed; the atomics stay in flight
-                wait_vm0();                                                      // (the atomics went out channels ago)
-                EXP_T(4);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(gn[i]) : "v"(gnn[i]));   // here, not hoisted into the adds
-                lds_barrier();                                                   // adds of quad q landed, max of quad q+1 published, set of quad q-1 zero
-                EXP_T(5);
-            } else {
-                if (q + 2 < nq) { if constexpr (MVHMR_BWD_ASYNC_G) load_g_async(q + 2); else load_g(q + 2); }
-                EXP_T(1);                                                        // scales, DMA request, adds + Jacobian issued
-                if constexpr (kExpB & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
-                lds_barrier();                                                   // adds of quad q landed; max of quad q+1 published
-                EXP_T(2);                                                        // barrier 1
-                flush_quad(q, inv_ch, poisoned);
-                if (tid < 4) sh->aux[aset * 4 + tid] = 0;                        // read by every wave before the barrier above
-                // window q+2 and grad_out q+2 (requested before this quad's atomics) have landed; the atomics stay in flight
-                EXP_T(3);                                                        // flush issued
-                wait_vmcnt((kExpB & 3) ? 0 : n_dyn);
-                if (MVHMR_BWD_ASYNC_G && q + 2 < nq) take_g();
-                EXP_T(4);                                                        // window q+2 / grad_out q+2 landed
-                if constexpr (kExpB & 8) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
-                lds_barrier();
-                EXP_T(5);                                                        // barrier 2
-            }
+            if (q + 2 < nq) load_g(q + 2);
+            lds_barrier();                                                       // adds of quad q landed; max of quad q+1 published
+            flush_quad(q, inv_ch, poisoned);
+            if (tid < 4) sh->aux[aset * 4 + tid] = 0;                            // read by every wave before the barrier above
+            // window q+2 and grad_out q+2 (requested before this quad's atomics) have landed; the atomics stay in flight
+            wait_vmcnt(n_dyn);
+            lds_barrier();
             aset = aset_next;
         }
-        if constexpr (PSETS == 2) {                                              // the last quad's sums (its adds landed at the loop's last barrier)
-            int n_dyn = 0;
-            (void)n_dyn;
-            // same flush as in the loop, on the set of quad nq - 1
-            const int qf = nq - 1;
-            const int q_off = qf * HW * 16;
-            int *const pset = iplanes + (qf & 1) * 4 * plane_floats;
-#pragma unroll
-            for (int r = 0; r < MC; ++r) {
-                if (l_dst[r] < 0) continue;
-                const int *pl = pset + (lane & 3) * plane_floats + c_slot[r] + (lane >> 2);
-#pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    const unsigned off = (unsigned)__shfl((int)g_off[r], 16 * jj + (lane >> 2));
-                    const int iv = pl[16 * jj];
-                    const float val = (float)iv * inv_prev;
-                    if (pois_prev || iv != 0) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(val, rgk, (int)(off + ch4), q_off, 0);
-                }
-            }
-        }
-#if MVHMR_EXP_BWD & 64
-        if (lane == 0) {
-            for (int i = 0; i < 6; ++i) atomicAdd(&g_exp_timers[i], t_acc[i]);
-            atomicAdd(&g_exp_timers[6], 1ull);
-        }
-#endif
     } else {
         // ---- windows do not fit: scatter straight to the accumulator (its own function: keeps its registers -- 16 tap
         // offsets on top of the weights -- out of the fast path's allocation, which otherwise spills in the quad loop)
@@ -730,14 +567,14 @@ k_quad_planar_to_planar(const float4 *__restrict__ src, TF *__restrict__ dst, in
 inline int grad_band(const Problem &p) { return (size_t)4 * p.H * 33 * sizeof(float) <= 64 * 1024 ? 32 : 8; }
 
 namespace {
-constexpr int kNTb = (kExpB & 128) ? 512 : 1024;      // 2 / 4 views
+constexpr int kNTb = 1024;                            // 2 / 4 views
 constexpr int kNTb8 = 512;                            // 8 views: 4 x 4 x 32 bricks, 256 VGPRs per lane, ONE feature window in LDS
 
 // z extent of the bricks: 8 x 8 x 16 (2 / 4 views) or 8 x 4 x 16 (8 views) when the volume divides (fp16 grad_out then comes in
 // 32-B runs: still hidden, 18.1 -> 15.1 ms like fp32), 4 x BY x 32 otherwise
 int bwd_brick_z(const Problem &p)
 {
-    const int by = (p.V > 4 || (kExpB & 128)) ? 4 : 8, nt = p.V > 4 ? kNTb8 : kNTb;
+    const int by = p.V > 4 ? 4 : 8, nt = p.V > 4 ? kNTb8 : kNTb;
     if (p.X % 8 == 0 && p.Y % by == 0 && p.Z % 16 == 0) return 16;
     const int by32 = nt / 128;
     if (p.X % kBX == 0 && p.Y % by32 == 0 && p.Z % kBZ == 0) return kBZ;
@@ -756,7 +593,7 @@ hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj,
     constexpr int BX = bwd_brick_x(BZ), BY = NT / (BZ * BX);
     const int nbx = (p.X + BX - 1) / BX, nby = (p.Y + BY - 1) / BY, nbz = (p.Z + BZ - 1) / BZ;
     const int bps = nbx * nby * nbz, total = bps * p.B;
-    const int lds_bytes = bwd_lds_bytes(NT, VT);
+    const int lds_bytes = kBwdLdsBytes;
     const size_t lds = (size_t)lds_bytes + sizeof(BrickShared<VT>);
     auto kern = k_bwd_brick<METHOD, VT, NT, TO, BZ>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
@@ -846,7 +683,7 @@ GateGeom brick_bwd_gate_geom(const Problem &p)
     GateGeom g;
     g.bz = bwd_brick_z(p);
     g.bx = bwd_brick_x(g.bz); g.by = nt / (g.bz * g.bx); g.column_major = 1; g.view_group = 0; g.parity_rows = 0;
-    g.cap_slots = bwd_cap_slots(nt, g.bz, p.V);
+    g.cap_slots = bwd_cap_slots(nt, g.bz);
     g.max_chunks = brick_chunks_per_wave(nt) * (nt / 64);
     return g;
 }
