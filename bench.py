@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--cpu-sample-batch", type=int, default=8, help="samples of the workload timed on the host (about 15 s)")
     ap.add_argument("--train-step", action="store_true", help="time one aggregator training step (fwd + bwd + grad all-reduce)")
     ap.add_argument("--in-channels", type=int, default=None, help="--train-step: input channels of the 1x1 conv (default: --channels)")
+    ap.add_argument("--soak-ms", type=float, default=1000.0,
+                    help="untimed steps run for about this long before the warm-up: the chip reaches its sustained clock (this path is power-limited, "
+                         "DESIGN.md 5.1) and an activity sampler beside the run sees it busy")
     ap.add_argument("--rccl-selftest", action="store_true",
                     help="one rank, one GPU: initialise the 'nccl' (= RCCL) backend with world size 1 and run the path's collective on the device "
                          "(proves init_process_group, the IPC-mode pin and the flat-buffer all-reduce load and run on this pool; no scaling number)")
@@ -363,6 +366,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    t_soak = time.perf_counter()
+    while (time.perf_counter() - t_soak) * 1e3 < a.soak_ms:          # untimed; the queue is drained every 16 steps so the loop tracks wall time
+        for _ in range(16):
+            step()
+        torch.cuda.synchronize()
     for _ in range(a.warmup):
         step()
     barrier()
@@ -397,7 +405,7 @@ def main():
                    "kernel_variant": "brick" if variant == 2 else "gather", "input_layout": "BVCHW (reference contract)"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "k_fwd_brick" if variant == 2 else "k_fwd_gather", "kernel_ms": round(k_main, 4),
+                     "kernel": (L.mvhmr_unproject_forward_kernel_name(ctypes.byref(d_k)) or b"?").decode(), "kernel_ms": round(k_main, 4),
                      "kernel_ms_min": round(float(np.min(k_all)), 4), "layout_pass_ms": round(k_layout, 4), "algorithmic_bytes": alg_bytes,
                      "step_frac": round(alg_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
     }
@@ -450,10 +458,19 @@ def main():
         if os.path.exists(traffic):
             try:
                 tj = json.load(open(traffic))
-                if tj.get("workload_key") == "%d-%d-%d-%d-%d-%s" % (S, C, V, HW, B, a.dtype):
+                md5_path = os.path.join(ROOT, "multiviewhmr_amd", "lib", "sources.md5")
+                md5_now = open(md5_path).read().strip() if os.path.exists(md5_path) else None
+                if tj.get("workload_key") != "%d-%d-%d-%d-%d-%s" % (S, C, V, HW, B, a.dtype):
+                    pass
+                elif tj.get("sources_md5") != md5_now or tj.get("kernel_name") != result["roofline"]["kernel"]:
+                    # counters taken from other kernel sources than the library this run loaded: not replayed
+                    result["roofline"]["traffic_source"] = "not replayed: %s was taken at sources %s (commit %s), this library is %s" % (
+                        os.path.relpath(traffic, ROOT), tj.get("sources_md5"), tj.get("commit"), md5_now)
+                else:
                     result["roofline"]["traffic"] = tj.get("hbm_bytes_per_launch")
-                    result["roofline"]["traffic_source"] = "replayed from %s (separate rocprofv3 --pmc passes, not this run)" % os.path.relpath(traffic, ROOT)
-                    if "backward" in result and "backward" in tj:
+                    result["roofline"]["traffic_source"] = "replayed from %s, taken at commit %s = these kernel sources (separate rocprofv3 --pmc passes, not this run)" % (
+                        os.path.relpath(traffic, ROOT), tj.get("commit"))
+                if result["roofline"].get("traffic") is not None and "backward" in result and "backward" in tj:
                         result["backward"]["traffic"] = tj["backward"].get("hbm_bytes_per_launch")
                         result["backward"]["traffic_source"] = result["roofline"]["traffic_source"]
             except Exception:

@@ -120,6 +120,11 @@ typedef struct mvhmr_unproject_desc {
     int32_t variant;     /* mvhmr_variant_t                     */
 } mvhmr_unproject_desc;
 
+/* Name of the kernel family the forward launches for this descriptor ("k_fwd_ws", "k_fwd_brick", "k_fwd_brick_groups", "k_fwd_gather";
+ * for MVHMR_VARIANT_AUTO on gated shapes: the brick-side kernel the device-side gate may select): lets a profiler harness match
+ * rocprofv3 kernel names without knowing the dispatch rules.  Static storage; NULL for an invalid descriptor. */
+const char *mvhmr_unproject_forward_kernel_name(const mvhmr_unproject_desc *desc);
+
 /* 1 when mvhmr_unproject_backward[_cuboid] serves this descriptor (layout x variant x shape), else 0: lets set-up code choose a
  * route before any tensor exists (the forward's counterpart is mvhmr_unproject_selected_variant > 0). */
 int mvhmr_unproject_backward_supported(const mvhmr_unproject_desc *desc);

@@ -24,6 +24,7 @@ EXPORTS = (
     "mvhmr_unproject_forward_cuboid", "mvhmr_unproject_backward_cuboid",
     "mvhmr_conv1x1_to_quad", "mvhmr_conv1x1_to_quad_supported", "mvhmr_conv1x1_planar", "mvhmr_conv1x1_planar_supported", "mvhmr_conv1x1_wgrad", "mvhmr_conv1x1_wgrad_supported", "mvhmr_unproject_query_variant_cuboid",
     "mvhmr_unproject_backward_supported", "mvhmr_triangulate_dlt", "mvhmr_triangulate_dlt_weighted",
+    "mvhmr_unproject_forward_kernel_name",
 )
 
 
@@ -58,6 +59,8 @@ def lib():
     L.mvhmr_unproject_backward_workspace_bytes.argtypes = [dp]
     L.mvhmr_unproject_selected_variant.restype = ctypes.c_int
     L.mvhmr_unproject_selected_variant.argtypes = [dp]
+    L.mvhmr_unproject_forward_kernel_name.restype = ctypes.c_char_p
+    L.mvhmr_unproject_forward_kernel_name.argtypes = [dp]
     L.mvhmr_unproject_backward_supported.restype = ctypes.c_int
     L.mvhmr_unproject_backward_supported.argtypes = [dp]
     L.mvhmr_unproject_query_variant.restype = ctypes.c_int

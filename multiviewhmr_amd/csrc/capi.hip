@@ -279,6 +279,17 @@ int mvhmr_unproject_query_variant(const mvhmr_unproject_desc *desc, const float 
     return host <= brick_count(p, g) / 8 ? MVHMR_VARIANT_BRICK : MVHMR_VARIANT_GATHER;
 }
 
+const char *mvhmr_unproject_forward_kernel_name(const mvhmr_unproject_desc *desc)
+{
+    Problem p;
+    if (check_desc(desc, &p) != MVHMR_OK) return nullptr;
+    const int variant = pick_variant(desc, p);
+    if (variant_conflict(desc, p, variant) != MVHMR_OK) return nullptr;
+    if (variant != MVHMR_VARIANT_BRICK) return "k_fwd_gather";
+    if (brick_fwd_ws_shape(p)) return "k_fwd_ws";
+    return p.V > 4 ? "k_fwd_brick_groups" : "k_fwd_brick";
+}
+
 int mvhmr_unproject_backward_supported(const mvhmr_unproject_desc *desc)
 {
     Problem p;

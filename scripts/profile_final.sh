@@ -1,11 +1,13 @@
 #!/bin/bash
-# usage: scripts/profile_final.sh <tag>   (GPU box, repo root): kernel-trace stats of the default bench run + HBM-side traffic counters of
-# the forward and backward kernels (separate --pmc passes, as MI355X_MICROARCH.md prescribes) -> gpurun_out/<tag>_final/
+# usage: GIT_HEAD=<hash> scripts/profile_final.sh <tag>   (GPU box, repo root): kernel-trace stats of the default bench run + HBM-side traffic
+# counters of the forward and backward kernels (separate --pmc passes, as MI355X_MICROARCH.md prescribes) -> gpurun_out/<tag>_final/,
+# including a ready-made traffic_latest.json (copy it to profiles/) stamped with the library's sources.md5 and the commit: bench.py
+# replays it only for the library it was taken from.  Under rocprofv3 the program goes directly behind `--`.
 tag=${1:-final}
 out=$GRAFT_REPO_ROOT/gpurun_out/${tag}_final
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-check"
+B="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-check --soak-ms 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- $B --steps 20 --warmup 5 > $out/stats.log 2>&1
 echo "stats exit $?"
 timeout -k 10 240 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- $B --steps 2 --warmup 1 > $out/fetch.log 2>&1
@@ -15,9 +17,9 @@ echo "write exit $?"
 timeout -k 10 240 rocprofv3 --pmc TCC_EA0_ATOMIC_sum --output-format csv -d $out/atomic -- $B --steps 2 --warmup 1 > $out/atomic.log 2>&1
 echo "atomic exit $?"
 cd $GRAFT_REPO_ROOT
-python3 - "$out" <<'PY'
+python3 - "$out" "${GIT_HEAD:-unknown}" <<'PY'
 import csv, glob, json, collections, os, sys
-out = sys.argv[1]
+out, head = sys.argv[1], sys.argv[2]
 def counters(d):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
@@ -34,5 +36,32 @@ for k in fe:
 json.dump(res, open(out + "/traffic_raw.json", "w"), indent=1)
 for k, v in res.items():
     print("%-66s FETCH %12.0f KB  WRITE %12.0f KB  ATOMIC %12.0f (n=%d)" % (k, v["FETCH_SIZE_KB_raw"], v["WRITE_SIZE_KB"], v["TCC_EA0_ATOMIC"], v["dispatches"]))
+def pick(sub):
+    ks = [k for k in res if sub in k]
+    return (ks[0], res[ks[0]]) if ks else (None, None)
+# north-star workload of bench.py's defaults
+B, V, C, HW, S = 32, 4, 256, 96, 64
+feat_bytes = B * V * C * HW * HW * 4
+alg_f = feat_bytes + B * S ** 3 * 12 + B * V * 48 + B * C * S ** 3 * 4
+alg_b = B * C * S ** 3 * 4 + feat_bytes + B * S ** 3 * 12 + B * V * 48 + feat_bytes
+kl, lay = pick("k_to_quad_planar_t_band")
+factor = feat_bytes / (lay["FETCH_SIZE_KB_raw"] * 1024) if lay else 2.0        # FETCH_SIZE calibration on a kernel whose reads are known
+md5 = open("multiviewhmr_amd/lib/sources.md5").read().strip()
+tj = {"workload_key": "%d-%d-%d-%d-%d-f32" % (S, C, V, HW, B), "commit": head, "sources_md5": md5}
+for name, key in (("k_fwd_ws", None), ("k_fwd_brick", None)):
+    kf, f = pick("mvhmr::" + name + "<")
+    if f:
+        tj.update({"kernel_name": name, "kernel": kf, "FETCH_SIZE_KB_raw": f["FETCH_SIZE_KB_raw"], "WRITE_SIZE_KB": f["WRITE_SIZE_KB"],
+                   "hbm_bytes_per_launch": int(f["FETCH_SIZE_KB_raw"] * 1024 * factor + f["WRITE_SIZE_KB"] * 1024), "algorithmic_bytes": alg_f})
+        break
+tj["correction"] = ("gfx950: FETCH_SIZE reports about 1/2 of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM section); calibrated in the same passes on "
+                    "k_to_quad_planar_t_band: %.0f KB reported for %d B read (factor %.3f); WRITE_SIZE exact" % (lay["FETCH_SIZE_KB_raw"] if lay else -1, feat_bytes, factor))
+kb, b = pick("k_bwd_brick")
+if b:
+    tj["backward"] = {"kernel": kb, "FETCH_SIZE_KB_raw": b["FETCH_SIZE_KB_raw"], "WRITE_SIZE_KB": b["WRITE_SIZE_KB"], "TCC_EA0_ATOMIC_64B_requests": b["TCC_EA0_ATOMIC"],
+                      "hbm_bytes_per_launch": int(b["FETCH_SIZE_KB_raw"] * 1024 * factor + b["WRITE_SIZE_KB"] * 1024), "algorithmic_bytes": alg_b}
+tj["source"] = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_EA0_ATOMIC_sum (separate passes, scripts/profile_final.sh), bench.py --steps 2 --warmup 1, mean over the dispatches of each kernel"
+json.dump(tj, open(out + "/traffic_latest.json", "w"), indent=1)
+print(json.dumps(tj, indent=1))
 PY
 f=$(ls $out/stats/*/*kernel_stats.csv | head -1); cut -c1-150 $f | head -14
