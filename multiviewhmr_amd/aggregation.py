@@ -12,6 +12,7 @@ torch.autograd.Function.  There is no CPU / eager fallback: the call raises if t
 a HIP device or the library is not built.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -100,9 +101,35 @@ def _make_desc(features, coord_volumes, method, out_dtype, layout, variant):
 _DTYPES = {_capi.F32: torch.float32, _capi.F16: torch.float16, _capi.BF16: torch.bfloat16}
 
 
+def _load_native():
+    """The PyTorch-ROCm C++ extension over the C ABI (csrc_ext/mvhmr_torch_ext.cpp, built in-tree by multiviewhmr_amd.build.build_ext):
+    the per-call host work -- descriptor, output and workspace from the caching allocator, current stream, the C-ABI call -- in C++.
+    Without it (not built, or MVHMR_NO_NATIVE_EXT=1) the same C-ABI calls are made through ctypes: both are the HIP path."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib_ext", "mvhmr_torch_ext.so")
+    if os.environ.get("MVHMR_NO_NATIVE_EXT") == "1" or not os.path.exists(path) or not os.path.exists(_capi.LIB_PATH):
+        return False
+    torch.ops.load_library(path)
+    if torch.ops.mvhmr_native.abi_version() != _capi.ABI_VERSION:
+        raise RuntimeError("mvhmr_torch_ext.so speaks ABI %d, this package %d: rebuild (python -m multiviewhmr_amd.build)"
+                           % (torch.ops.mvhmr_native.abi_version(), _capi.ABI_VERSION))
+    return True
+
+
+_NATIVE = _load_native()
+
+
+def _native_args(features, layout, like, coords, method, out_dtype, variant):
+    B, V, C, Hf, Wf = like.shape
+    read = features.permute(0, 1, 3, 4, 2) if layout == _capi.LAYOUT_BVHWC else features     # the contiguous view the library reads
+    return (read, None, coords, B, V, C, Hf, Wf, method, _dtype_code(like.dtype), out_dtype, layout, variant)
+
+
 def _op_forward(features, proj, coords, method, out_dtype, variant):
     L = _capi.lib()
     features, layout, like = _feature_layout(features, coords, method, _DTYPES[out_dtype], variant)
+    if _NATIVE:
+        a = _native_args(features, layout, like, coords, method, out_dtype, variant)
+        return torch.ops.mvhmr_native.unprojection(a[0], proj, *a[2:])
     desc = _make_desc(like, coords, method, _DTYPES[out_dtype], layout, variant)
     B, C = like.shape[0], like.shape[2]
     with torch.cuda.device(features.device):
@@ -117,8 +144,11 @@ def _op_backward(grad_out, features, proj, coords, method, out_dtype, variant):
     """gradient w.r.t. features only: proj_matricies and coord_volumes come from numpy / arange in the caller and never require grad"""
     L = _capi.lib()
     features, layout, like = _feature_layout(features, coords, method, _DTYPES[out_dtype], variant)
-    desc = _make_desc(like, coords, method, _DTYPES[out_dtype], layout, variant)
     grad_out = grad_out.contiguous()
+    if _NATIVE:
+        a = _native_args(features, layout, like, coords, method, out_dtype, variant)
+        return torch.ops.mvhmr_native.unprojection_backward(grad_out, a[0], proj, *a[2:])
+    desc = _make_desc(like, coords, method, _DTYPES[out_dtype], layout, variant)
     with torch.cuda.device(features.device):
         # same strides as what the library read -- except quad-planar features, whose gradient comes back planar
         grad_features = torch.empty(like.shape, dtype=like.dtype, device=like.device) if layout == _capi.LAYOUT_QUAD else torch.empty_like(features)

@@ -104,3 +104,15 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_capi, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _capi.lib()
+
+
+def test_torch_extension_builds_and_speaks_the_abi():
+    """the PyTorch-ROCm C++ extension over the C ABI (csrc_ext/mvhmr_torch_ext.cpp) builds in-tree without a GPU and registers its ops"""
+    import torch
+    from multiviewhmr_amd import build
+    ext = build.build_ext()
+    assert os.path.exists(ext)
+    torch.ops.load_library(ext)
+    assert torch.ops.mvhmr_native.abi_version() == _capi.ABI_VERSION
+    for name in ("unprojection", "unprojection_backward"):
+        assert hasattr(torch.ops.mvhmr_native, name)

@@ -1809,3 +1809,34 @@ def test_mean_over_absent_views_is_one_division_by_the_real_views(views, gpu):
     aggregation.unprojection(fb, p, c, aggregation_method="mean", variant="brick").backward(torch.from_numpy(go).to(gpu))
     gref = cport.backward(go, feats, proj, coords, "mean")
     record_err("mean V%d brick bwd" % views, _err(fb.grad.cpu().numpy(), gref), _bound(gref))
+
+
+def test_native_extension_is_the_route_and_equals_the_ctypes_route(gpu, monkeypatch):
+    """north_star: "drop-in ... via a PyTorch-ROCm C++/HIP extension".  The custom ops' host work runs in lib_ext/mvhmr_torch_ext.so
+    (csrc_ext/mvhmr_torch_ext.cpp over the C ABI); the ctypes route makes the same C-ABI calls: bit-equal forward, and backward up
+    to the float atomics' order"""
+    assert aggregation._NATIVE, "the C++ extension was not built / not found beside the package"
+    d = load_golden("unproj", "bricks_v4c8")
+    p, c, go = _dev(d, "proj", gpu), _dev(d, "coords", gpu), _dev(d, "grad_out", gpu)
+    outs, grads = [], []
+    for native in (True, False):
+        monkeypatch.setattr(aggregation, "_NATIVE", native)
+        for feats in (_dev(d, "features", gpu), _dev(d, "features", gpu).permute(0, 1, 3, 4, 2).contiguous().permute(0, 1, 4, 2, 3)):
+            f = feats.detach().requires_grad_(True)
+            out = aggregation.unprojection(f, p, c)
+            out.backward(go)
+            outs.append(out.detach()); grads.append(f.grad)
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])                  # planar, channels-last
+    record_err("native vs ctypes route, planar bwd", float((grads[0] - grads[2]).abs().max()), 1e-5)
+    record_err("native vs ctypes route, channels-last bwd", float((grads[1] - grads[3]).abs().max()), 1e-5)
+    assert grads[1].stride() == grads[3].stride()                                            # channels-last gradient for channels-last features
+    record_err("native route vs golden", _err(outs[0].cpu().numpy(), d["out_softmax"]), TOL)
+    # the C ABI trusts its descriptor: the extension checks every tensor against it BEFORE anything is launched
+    fe = _dev(d, "features", gpu)
+    B, V, C, H, W = fe.shape
+    with pytest.raises(RuntimeError, match="features hold"):
+        torch.ops.mvhmr_native.unprojection(fe, p, c, B, V, C, H + 1, W, 0, 0, 0, 0, 2)
+    with pytest.raises(RuntimeError, match="proj_matricies"):
+        torch.ops.mvhmr_native.unprojection(fe, p[:, :1].contiguous(), c, B, V, C, H, W, 0, 0, 0, 0, 2)
+    with pytest.raises(RuntimeError, match="mvhmr_unproject"):                               # library errors surface as RuntimeError
+        torch.ops.mvhmr_native.unprojection(fe, p, c, B, V, C, H, W, 7, 0, 0, 0, 2)         # unknown aggregate
