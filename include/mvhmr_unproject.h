@@ -131,7 +131,8 @@ int mvhmr_unproject_backward_supported(const mvhmr_unproject_desc *desc);
 
 /* Bytes of device scratch forward / backward need for this problem (0 is possible).  Forward: at most one fp32 copy of the features.
  * Backward: a feature copy + an fp32 gradient accumulator of the same size on the brick route; on the coarse-grid (plane) route a tap
- * table and the Jacobian stream, V x the size of grad_out in fp32 (1.07 GB for BASELINE configs[1]) -- ask, do not guess. */
+ * table and one slab of the Jacobian stream (V x the slab's share of grad_out in fp32, at most ~256 MB: 0.27 GB for BASELINE configs[1]) --
+ * ask, do not guess. */
 size_t mvhmr_unproject_forward_workspace_bytes(const mvhmr_unproject_desc *desc);
 size_t mvhmr_unproject_backward_workspace_bytes(const mvhmr_unproject_desc *desc);
 

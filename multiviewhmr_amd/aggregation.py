@@ -7,9 +7,11 @@
 Same names, argument meaning, return shapes/dtypes, state-dict keys and quirks (SURVEY.md section 8a,
 Q1-Q6).  What differs is HOW: the b x v Python loop with ~20 ATen launches per iteration and the
 (V,C,X,Y,Z) intermediates is one fused HIP kernel launch behind the C ABI of include/mvhmr_unproject.h
-(forward), and one more for the gradient w.r.t. `features` (backward), wrapped in a
-torch.autograd.Function.  There is no CPU / eager fallback: the call raises if the tensors are not on
-a HIP device or the library is not built.
+(forward), and one more for the gradient w.r.t. `features` (backward), exposed as torch.library custom ops
+(mvhmr::unprojection / mvhmr::unprojection_cuboid + their _backward ops, with fake / meta shape functions and a
+registered autograd formula) whose host side runs in the PyTorch-ROCm C++ extension csrc_ext/mvhmr_torch_ext.cpp
+(or, without it, through the ctypes binding of the same C ABI).  There is no CPU / eager fallback: the call raises
+if the tensors are not on a HIP device or the library is not built.
 """
 import ctypes
 import os
