@@ -132,7 +132,7 @@ __device__ __forceinline__ float ws_softmax_safe(const float (&s)[V])
 
 // one voxel sampled straight from global memory (windows that do not fit LDS); `unscale` = ln 2 for a prescaled copy, else 1
 template <int METHOD, int VT, typename TO>
-__device__ __attribute__((noinline)) void ws_slow_voxel(const float4 *fk, TO *obase, const float (*proj)[12], const Coords &coords, int b,
+__device__ __attribute__((noinline)) void ws_slow_voxel(const float4 *fk, TO *obase, const float (*proj)[12], const Coords coords, int b,   // by value: a reference would pin the kernel's copy in scratch
                                                         long long N, unsigned vox, int nq, int nqv, int H, int W, int nv, float unscale)
 {
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
@@ -190,6 +190,21 @@ struct WsBrick {
     int b, kx, ky, kz, nq, H, W, X, Y, Z, nv;
     unsigned chan_bytes, lds_base;
 };
+
+// the cold path of a compute wave: its units' voxels one by one through ws_slow_voxel
+template <int METHOD, int VT, typename TO>
+__device__ __attribute__((noinline)) void ws_slow_units(const WsBrick<TO> B, const float (*proj)[12], const Coords coords, int u0, int nunits, int dcol,
+                                                        int zin, float unscale)
+{
+    const int vz = B.kz * kBZ + zin;
+    for (int u = 0; u < nunits; ++u) {
+        const int unit = u0 + u;
+        const int vx = B.kx * 8 + 2 * (unit & 3) + dcol, vy = B.ky * 8 + (unit >> 2);
+        if (vx < B.X && vy < B.Y && vz < B.Z)
+            ws_slow_voxel<METHOD, VT, TO>(B.fk, B.obase, proj, coords, B.b, B.N, (unsigned)(((long long)vx * B.Y + vy) * B.Z + vz), B.nq, B.nq, B.H, B.W,
+                                          B.nv, unscale);
+    }
+}
 
 // ==================================================================== memory waves (NMW of them; wave = 0 .. NMW - 1)
 template <int VT, typename TO, int NMW>
@@ -295,7 +310,7 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
     unsigned vox[NVOX];
     bool inside[NVOX];
     float w00[NVOX][VT], w01[NVOX][VT], w10[NVOX][VT], w11[NVOX][VT];
-    int tx[NVOX][VT], ty[NVOX][VT];
+    int txy[NVOX][VT];
     unsigned valid = 0;
     {
         int bxmin[VT], bymin[VT], bxmax[VT], bymax[VT];
@@ -315,12 +330,15 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
             for (int v = 0; v < VT; ++v) {
                 const Taps t = make_taps(sh->proj[v], c0, c1, c2, B.H, B.W);
                 w00[u][v] = t.w00; w01[u][v] = t.w01; w10[u][v] = t.w10; w11[u][v] = t.w11;
-                tx[u][v] = t.rx0; ty[u][v] = t.ry0;
+                txy[u][v] = (t.rx0 & 0xFFFF) | (t.ry0 << 16);                  // nw tap, each in [-1, 32 766]: one register until the windows are known
                 if (t.any && inside[u] && v < nv) {
                     valid |= 1u << (u * VT + v);
                     bxmin[v] = t.rx0 < bxmin[v] ? t.rx0 : bxmin[v]; bxmax[v] = t.rx0 > bxmax[v] ? t.rx0 : bxmax[v];
                     bymin[v] = t.ry0 < bymin[v] ? t.ry0 : bymin[v]; bymax[v] = t.ry0 > bymax[v] ? t.ry0 : bymax[v];
                 }
+                // one projection at a time: interleaved by the scheduler, the 4 NVOX independent make_taps spill ~100 B per lane
+                // (0.4 GB of scratch writes per launch at the north star: profiles/r05_fwd_ablations.txt G)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
@@ -338,10 +356,11 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
     ws_size_windows<VT>(sh, win);
 
     if (!win.fits) {
-        // ---- windows do not fit the LDS pool: sample straight from global memory (the memory waves have left)
-#pragma unroll 1
-        for (int u = 0; u < NVOX; ++u)
-            if (inside[u]) ws_slow_voxel<METHOD, VT, TO>(B.fk, B.obase, sh->proj, coords, B.b, B.N, vox[u], B.nq, B.nq, B.H, B.W, nv, PRE ? kLn2 : 1.f);
+        // ---- windows do not fit the LDS pool: sample straight from global memory (the memory waves have left).  ONE call that rebuilds
+        // the voxel indices itself and is followed by the return: nothing of the fast path lives across it (the first form, a loop of calls
+        // over vox[] / inside[], made the allocator spill ~50 registers per lane in front of this branch on EVERY brick: 0.4 GB of scratch
+        // writes per launch at the north star)
+        ws_slow_units<METHOD, VT, TO>(B, sh->proj, coords, u0, NVOX, dcol, zin, PRE ? kLn2 : 1.f);
         return;
     }
 
@@ -369,8 +388,9 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
 #pragma unroll
         for (int u = 0; u < NVOX; ++u) {
             const bool ok = (valid >> (u * VT + v)) & 1u;
-            const int yr = ty[u][v] - win.wy0[v];
-            const int sc = win.slot0[v] + (tx[u][v] - win.wx0[v]) * win.ws[v];
+            const int tx = (int)(short)(txy[u][v] & 0xFFFF), ty = txy[u][v] >> 16;
+            const int yr = ty - win.wy0[v];
+            const int sc = win.slot0[v] + (tx - win.wx0[v]) * win.ws[v];
             int a0 = ok ? kZeroBytes + (sc + ((yr + 1) >> 1)) * 16 : 0;
             int a1 = ok ? kZeroBytes + (sc + win.whp[v] + (yr >> 1)) * 16 : 0;
             if (yr & 1) {
