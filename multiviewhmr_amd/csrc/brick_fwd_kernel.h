@@ -598,10 +598,17 @@ bool brick_fwd_grouped(const Problem &p);
 template <int METHOD, int VT, typename TO>
 hipError_t launch_fwd_groups_instance(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s);
 
-// 3 / 4 views, fp32 volume, chip-filling launches: the wave-specialised kernel (brick_fwd_ws.h); PRE: the staged copy is multiplied by log2(e)
+// 3 / 4 views, chip-filling launches: the wave-specialised kernel (brick_fwd_ws.h); PRE: the staged copy is multiplied by log2(e)
 bool brick_fwd_ws_shape(const Problem &p);
+template <int METHOD, bool PRE, typename TO>
+hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s);
 template <int METHOD, bool PRE>
-hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const Coords &coords, float *out, const Problem &p, hipStream_t s);
+hipError_t launch_fwd_ws_storage(const float4 *featK, const float *proj, const Coords &coords, void *out, const Problem &p, hipStream_t s)
+{
+    return p.out_f16    ? launch_fwd_ws_instance<METHOD, PRE, __half>(featK, proj, coords, (__half *)out, p, s)
+           : p.out_bf16 ? launch_fwd_ws_instance<METHOD, PRE, bf16_t>(featK, proj, coords, (bf16_t *)out, p, s)
+                        : launch_fwd_ws_instance<METHOD, PRE, float>(featK, proj, coords, (float *)out, p, s);
+}
 
 // one aggregation method: views x storage type x voxels per lane
 template <int METHOD>
@@ -610,10 +617,10 @@ hipError_t launch_fwd_method(const void *featK_, const float *proj, const Coords
     const float4 *featK = static_cast<const float4 *>(featK_);
     if (brick_fwd_ws_shape(p)) {
         if constexpr (METHOD == AGG_SOFTMAX) {
-            if (p.feat_log2e) return launch_fwd_ws_instance<METHOD, true>(featK, proj, coords, (float *)out, p, s);
+            if (p.feat_log2e) return launch_fwd_ws_storage<METHOD, true>(featK, proj, coords, out, p, s);
         }
         if (p.feat_log2e) return hipErrorNotSupported;
-        return launch_fwd_ws_instance<METHOD, false>(featK, proj, coords, (float *)out, p, s);
+        return launch_fwd_ws_storage<METHOD, false>(featK, proj, coords, out, p, s);
     }
     if (p.feat_log2e) return hipErrorNotSupported;                               // only the wave-specialised softmax reads a prescaled copy
 #define MVHMR_FWD_CASE(NVIEWS, NTHR, NV)                                                                                                 \

@@ -210,7 +210,7 @@ __device__ __attribute__((noinline)) void ws_slow_units(const WsBrick<TO> B, con
 template <int VT, typename TO, int NMW>
 __device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdShared<VT> *sh, const WsBrick<TO> &B, int wave, int lane)
 {
-    constexpr int MC = kWsChunkTotal / NMW, NS = 32 / NMW;                       // pieces / store instructions per wave and quad
+    constexpr int MC = kWsChunkTotal / NMW;                                      // LDS-DMA pieces per wave and quad
     WsWindows<VT> win;
     ws_size_windows<VT>(sh, win);
     if (!win.fits) return;                                                       // the compute waves sample from global memory
@@ -248,16 +248,20 @@ __device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdSha
             if (rr < n_m) glds16_m0(src_n, go[rr], B.lds_base + (unsigned)(boff + kZeroBytes + (wave + rr * NMW) * 1024));
         src_n += HW;
     };
-    // ---- stores: instruction j = wave + NMW k (k < NS) writes channel j >> 3, brick row y = j & 7: lane = (x, z quad) reads
-    // R[j >> 3][(j & 7) * 8 + x][4 z4 ..] (1 KiB contiguous per instruction) and writes 16 B; 8 lanes = one 128-B run of z
-    const int xl = lane >> 3, z4 = lane & 7;
-    const int vx = B.kx * 8 + xl, vz = B.kz * kBZ + z4 * 4;
-    const unsigned voff = (vx < B.X && vz < B.Z) ? (unsigned)((((long long)vx * B.Y + B.ky * 8) * B.Z + vz) * (long long)sizeof(TO)) : 0xFFFFFFF0u;   // beyond num_records: dropped
+    // ---- stores.  fp32 volume: instruction j = wave + NMW k (k < NS = 32 / NMW) writes channel j >> 3, brick row y = j & 7: lane = (x, z quad)
+    // reads R[j >> 3][(j & 7) * 8 + x][4 z4 ..] (1 KiB contiguous per instruction) and writes 16 B; 8 lanes = one 128-B run of z.
+    // 16-bit volume: instruction j (k < NS = 16 / NMW) writes channel j >> 2, brick rows y = 2 (j & 3) + (lane >> 5): lane = (y bit, x, z octet)
+    // reads 8 results (32 B of R), rounds them once (from_f32's rounding) and writes 16 B; 4 lanes = one 64-B run of z.
+    constexpr bool kWide = sizeof(TO) == 4;
+    constexpr int NS = (kWide ? 32 : 16) / NMW, NR = kWide ? NS : 2 * NS;         // store instructions / 16-B reads of R per wave and quad
+    const int xl = kWide ? lane >> 3 : (lane >> 2) & 7, yl = kWide ? 0 : lane >> 5, zl = kWide ? (lane & 7) * 4 : (lane & 3) * 8;
+    const int vx = B.kx * 8 + xl, vz = B.kz * kBZ + zl;
+    const unsigned voff = (vx < B.X && vz < B.Z) ? (unsigned)((((long long)vx * B.Y + B.ky * 8 + yl) * B.Z + vz) * (long long)sizeof(TO)) : kDropOffset;   // beyond num_records: dropped
     const unsigned ystep = (unsigned)(B.Z * (int)sizeof(TO));
     int n_st = 0;                                                                // store instructions of this wave per quad
 #pragma unroll
-    for (int k = 0; k < NS; ++k) n_st += B.ky * 8 + ((wave + NMW * k) & 7) < B.Y ? 1 : 0;
-    const int r_rd = 2 * kWsBufBytes + wave * 1024 + lane * 16;
+    for (int k = 0; k < NS; ++k) n_st += B.ky * 8 + (kWide ? (wave + NMW * k) & 7 : 2 * ((wave + NMW * k) & 3)) < B.Y ? 1 : 0;
+    const int r_rd = 2 * kWsBufBytes + (kWide ? lane * 16 : yl * 1024 + xl * 128 + zl * 4);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
     dma(0);                                                                      // quad 0 -> buffer 0
@@ -269,10 +273,19 @@ __device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdSha
         }
         bare_barrier();                                                          // A(q): windows of quad q published; results of quad q - 1 complete
         // (the only barrier of the quad loop: the hand-back "R may be overwritten" is a counter, see below)
-        float4 res[NS];
+        float4 res[NR];
         if (q > 0) {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) res[k] = *reinterpret_cast<const float4 *>(smem + r_rd + k * NMW * 1024);
+            for (int k = 0; k < NS; ++k) {
+                const int jj = wave + NMW * k;
+                if constexpr (kWide) {
+                    res[k] = *reinterpret_cast<const float4 *>(smem + r_rd + jj * 1024);
+                } else {
+                    const int at = r_rd + (jj >> 2) * 8192 + (jj & 3) * 2048;
+                    res[2 * k] = *reinterpret_cast<const float4 *>(smem + at);
+                    res[2 * k + 1] = *reinterpret_cast<const float4 *>(smem + at + 16);
+                }
+            }
         }
         if (q < B.nq) {
             // R has been read (lgkmcnt(0)): tell the compute waves, which may then write quad q's results -- every lane adds 1, so the
@@ -284,11 +297,22 @@ __device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdSha
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(B.obase + (long long)((q - 1) * 4) * B.N, 0, (int)(4u * B.chan_bytes), 0x00020000);
 #pragma unroll
             for (int k = 0; k < NS; ++k) {
-                const int jj = wave + NMW * k, ys = jj & 7, ch = jj >> 3;
-                if (B.ky * 8 + ys < B.Y) {
-                    const u32x4 d = {__builtin_bit_cast(unsigned, res[k].x), __builtin_bit_cast(unsigned, res[k].y),
-                                     __builtin_bit_cast(unsigned, res[k].z), __builtin_bit_cast(unsigned, res[k].w)};
-                    __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)voff, (int)(ys * ystep + ch * B.chan_bytes), kStAux);
+                const int jj = wave + NMW * k;
+                if constexpr (kWide) {
+                    const int ys = jj & 7, ch = jj >> 3;
+                    if (B.ky * 8 + ys < B.Y) {
+                        const u32x4 d = {__builtin_bit_cast(unsigned, res[k].x), __builtin_bit_cast(unsigned, res[k].y),
+                                         __builtin_bit_cast(unsigned, res[k].z), __builtin_bit_cast(unsigned, res[k].w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)voff, (int)(ys * ystep + ch * B.chan_bytes), kStAux);
+                    }
+                } else {
+                    const int ys = 2 * (jj & 3), ch = jj >> 2;
+                    if (B.ky * 8 + ys < B.Y) {                                   // the pair's second row may still be outside: its lanes are dropped
+                        const u32x4 d = {pack2<TO>(res[2 * k].x, res[2 * k].y), pack2<TO>(res[2 * k].z, res[2 * k].w),
+                                         pack2<TO>(res[2 * k + 1].x, res[2 * k + 1].y), pack2<TO>(res[2 * k + 1].z, res[2 * k + 1].w)};
+                        const unsigned vo = B.ky * 8 + ys + yl < B.Y ? voff : kDropOffset;
+                        __builtin_amdgcn_raw_buffer_store_b128(d, rs, (int)vo, (int)(ys * ystep + ch * B.chan_bytes), kStAux);
+                    }
                 }
             }
         }
@@ -532,7 +556,6 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
     // nv <= VT views are real (3 views run the 4-view kernel): the others have no camera, no window and no part in the aggregate --
     // their samples read kAbsentSample from a slot of the zero region (softmax, max) or plain zeros (sum, mean)
     if (gated_off(gate)) return;
-    static_assert(sizeof(TO) == 4, "fp32 volumes (16-bit volumes: k_fwd_brick)");
     static_assert(!PRE || METHOD == AGG_SOFTMAX, "only the softmax reads a prescaled copy");
     constexpr int NMW = kWsMemWaves, NCW = CFG == 0 ? 8 : 12;
     extern __shared__ __align__(16) unsigned char smem[];
@@ -579,14 +602,14 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
 // ---- host side
 inline bool brick_fwd_ws_shape_impl(const Problem &p)
 {
-    // 3 or 4 views, fp32 volume, z rows of whole 16-B quads, enough bricks to fill the chip (fewer: k_fwd_brick splits the channels)
-    if (brick_view_slots(p.V) != 4 || p.out_f16 || p.out_bf16 || (p.Z & 3) || p.X <= kBX) return false;
+    // 3 or 4 views, z rows of whole 16-B store units (4 fp32 / 8 halves), enough bricks to fill the chip (fewer: k_fwd_brick splits the channels)
+    if (brick_view_slots(p.V) != 4 || (p.Z & ((p.out_f16 || p.out_bf16) ? 7 : 3)) || p.X <= kBX) return false;
     const long long bricks = (long long)((p.X + 7) / 8) * ((p.Y + 7) / 8) * ((p.Z + kBZ - 1) / kBZ) * p.B;
     return bricks >= 256;
 }
 
-template <int METHOD, bool PRE>
-hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const Coords &coords, float *out, const Problem &p, hipStream_t s)
+template <int METHOD, bool PRE, typename TO>
+hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s)
 {
     constexpr int VT = 4;
     const int nbx = (p.X + 7) / 8, nby = (p.Y + 7) / 8, nbz = (p.Z + kBZ - 1) / kBZ;
@@ -594,7 +617,7 @@ hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const 
     static_assert(sizeof(FwdShared<VT>) <= 1024 && kWsSyncOff + 16 <= 160 * 1024, "LDS layout");
     const size_t lds = (size_t)kWsSyncOff + 16;
     constexpr int CFG = MVHMR_WS_CFG;
-    auto kern = k_fwd_ws<METHOD, VT, float, PRE, CFG>;
+    auto kern = k_fwd_ws<METHOD, VT, TO, PRE, CFG>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;

@@ -346,13 +346,16 @@ template <> __device__ __forceinline__ float to_f32<__half>(__half x) { return _
 template <> __device__ __forceinline__ float to_f32<bf16_t>(bf16_t x) { return (float)x; }
 template <typename T> __device__ __forceinline__ T from_f32(float x);
 template <> __device__ __forceinline__ float from_f32<float>(float x) { return x; }
-template <> __device__ __forceinline__ __half from_f32<__half>(float x) { return __float2half_rn(x); }
+// fp16 results are the fp32 result rounded to nearest even, whatever produced it: the empty asm keeps hipcc from folding the last fp32
+// multiply into the conversion (v_fma_mixlo_f16 rounds the exact product once, which differs from "fp32, then fp16" exactly at ties)
+template <> __device__ __forceinline__ __half from_f32<__half>(float x) { asm("" : "+v"(x)); return __float2half_rn(x); }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float x) { return (bf16_t)x; }
 
 // two floats -> one dword of a 16-bit storage type (low half = a)
 template <typename T> __device__ __forceinline__ unsigned pack2(float a, float b);
 template <> __device__ __forceinline__ unsigned pack2<__half>(float a, float b)
 {
+    asm("" : "+v"(a), "+v"(b));                                                  // see from_f32<__half>
     const __half2 h = __floats2half2_rn(a, b);                                   // round to nearest even
     return __builtin_bit_cast(unsigned, h);
 }

@@ -51,7 +51,7 @@ __device__ __forceinline__ void build_records(TapRec *recs, const float *__restr
 __device__ __forceinline__ void store_streaming(float *p, float v) { __builtin_nontemporal_store(v, p); }
 __device__ __forceinline__ void store_streaming(__half *p, float v)
 {
-    __builtin_nontemporal_store(__half_as_ushort(__float2half_rn(v)), reinterpret_cast<unsigned short *>(p));
+    __builtin_nontemporal_store(__half_as_ushort(from_f32<__half>(v)), reinterpret_cast<unsigned short *>(p));   // fp32 first, then fp16
 }
 
 __device__ __forceinline__ void store_streaming(bf16_t *p, float v)

@@ -1720,6 +1720,35 @@ def test_wave_specialised_forward_vs_oracle(shape, mode, gpu):
     record_err(name + " auto", _err(auto.cpu().numpy(), ref), TOL)
 
 
+@pytest.mark.parametrize("shape", [
+    dict(B=16, V=4, C=8, H=48, W=48, vol=(32, 32, 32)),       # whole bricks
+    dict(B=9, V=3, C=12, H=40, W=56, vol=(20, 35, 40)),       # ragged in x, y (an odd row pair at the y edge) and z (z % 8 == 0), absent view
+    dict(B=4, V=4, C=4, H=400, W=400, vol=(64, 64, 32)),      # windows never fit: the compute waves' global-memory path stores 16-bit too
+])
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_wave_specialised_forward_16_bit_volumes(shape, mode, dt, gpu):
+    """k_fwd_ws with a 16-bit volume: the memory waves round the fp32 results once (8 per lane, one 16-B store): the volume is the fp32
+    volume of the same kernel rounded to nearest even, bit for bit; fp16 / bf16 features are widened by the layout pass as for k_fwd_brick"""
+    feats, proj, coords = _ring_problem(seed=57 + MODES.index(mode), **shape)
+    f, p, c = torch.from_numpy(feats).to(gpu), torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    # the two 16-bit storage modes of the ABI: fp16 features -> fp16 volume (autocast), fp32 features -> bf16 volume (VolumeGenerator.volume_dtype)
+    fin = f.half() if dt == torch.float16 else f
+    d = aggregation._make_desc(fin, tuple(c.shape[1:4]), _capi.AGG[mode], dt, _capi.LAYOUT_BVCHW, _capi.VARIANT["brick"])
+    assert _capi.lib().mvhmr_unproject_forward_kernel_name(ctypes.byref(d)) == b"k_fwd_ws"
+    o32 = aggregation.unprojection(fin, p, c, aggregation_method=mode, variant="brick", out_dtype=torch.float32)
+    out16 = aggregation.unprojection(fin, p, c, aggregation_method=mode, variant="brick", out_dtype=dt)
+    assert out16.dtype == dt and torch.equal(out16, o32.to(dt))
+    ref = cport.forward(fin.float().cpu().numpy(), proj, coords, mode)
+    name = "ws fwd %s storage %s V%d vol%s" % (mode, str(dt).split(".")[1], shape["V"], shape["vol"])
+    tol16 = (2.0 ** -10 if dt == torch.float16 else 2.0 ** -7) * max(1.0, float(np.abs(ref).max()))
+    record_err(name + " (fp32 volume)", _err(o32.cpu().numpy(), ref), TOL)
+    record_err(name, float((out16.float().cpu() - torch.from_numpy(ref).to(dt).float()).abs().max()), tol16)
+    auto = aggregation.unprojection(fin, p, c, aggregation_method=mode, variant="auto", out_dtype=dt)   # the gate sends the shape whose windows never fit to k_fwd_gather
+    record_err(name + " auto", float((auto.float().cpu() - torch.from_numpy(ref).to(dt).float()).abs().max()), tol16)
+    if shape["H"] < 400: assert torch.equal(auto, out16)
+
+
 def test_wave_specialised_softmax_over_the_whole_float_range(gpu):
     """as test_brick_softmax_over_the_whole_float_range, at a shape k_fwd_ws takes: exponentials relative to view 0 on prescaled
     samples, overflow test per channel pair (denominators below 2^60), the max form as the fallback"""
