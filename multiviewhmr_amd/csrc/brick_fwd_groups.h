@@ -86,7 +86,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
     if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
     const long long N = (long long)X * Y * Z;
-    const int HW = H * W, nqv = C >> 2, nq = nqv / ksplit, q0 = part * nq;
+    const int HW = H * W, nqv = (C + 3) >> 2, nq = (C >> 2) / ksplit, q0 = part * nq;   // nqv: the copy's quads per view; nq: this block's WHOLE quads
 
     if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
     if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }

@@ -131,6 +131,53 @@ struct FwdShared {
     float proj[VT][12];
 };
 
+// One voxel sampled straight from the staged copy in global memory, channel quads q_begin .. q_end - 1 of the nqv a view holds, channels
+// below C only: the path of bricks whose windows do not fit LDS (k_fwd_ws) and of the LAST, partial quad when C % 4 != 0 (k_fwd_tail,
+// launched behind every brick kernel: their loops run the C / 4 whole quads).  `unscale` = ln 2 for a copy prescaled by log2(e), else 1.  fk / obase: this sample's quad 0 /
+// channel 0.
+template <int METHOD, int VT, typename TO>
+__device__ __attribute__((noinline)) void fwd_global_voxel(const float4 *fk, TO *obase, const float (*proj)[12], const Coords coords, int b,   // by value: a reference would pin the kernel's copy in scratch
+                                                           long long N, unsigned vox, int q_begin, int q_end, int nqv, int C, int H, int W, int nv, float unscale)
+{
+    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    const int HW = H * W;
+    float c0, c1, c2;
+    voxel_xyz(coords, b, N, vox, c0, c1, c2);
+    float w00[VT], w01[VT], w10[VT], w11[VT];
+    int o00[VT], o01[VT], o10[VT], o11[VT];
+#pragma unroll
+    for (int v = 0; v < VT; ++v) {
+        const Taps t = make_taps(proj[v], c0, c1, c2, H, W);
+        w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
+        const int base = ((v < nv ? v : 0) * nqv) * HW;                         // an absent view reads view 0's pixels (and discards them)
+        o00[v] = base + t.x0 * H + t.y0; o01[v] = base + t.x1 * H + t.y0; o10[v] = base + t.x0 * H + t.y1; o11[v] = base + t.x1 * H + t.y1;
+    }
+    for (int q = q_begin; q < q_end; ++q) {
+        const float4 *src = fk + (long long)q * HW;
+        float s[4][VT];
+#pragma unroll
+        for (int v = 0; v < VT; ++v) {
+            const float4 a = src[o00[v]], bb = src[o01[v]], c = src[o10[v]], d = src[o11[v]];
+            s[0][v] = bilerp(a.x, bb.x, c.x, d.x, w00[v], w01[v], w10[v], w11[v]) * unscale;
+            s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[v], w01[v], w10[v], w11[v]) * unscale;
+            s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]) * unscale;
+            s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]) * unscale;
+            if (v >= nv) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s[i][v] = kAbsentReads ? kAbsentSample : 0.f;
+            }
+        }
+        TO *oq = obase + (long long)(q * 4) * N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float r;
+            if constexpr (METHOD == AGG_MEAN) r = __fdiv_rn(aggregate<AGG_SUM, VT>(s[i]), (float)nv);
+            else r = aggregate<METHOD, VT>(s[i]);
+            if (q * 4 + i < C) (oq + i * N)[vox] = from_f32<TO>(r);
+        }
+    }
+}
+
 // pool geometry shared by the kernel, the gate and the host: `slots` 16-B slots hold nb buffers of kZeroSlots + cap slots
 __host__ __device__ inline int fwd_cap3(int slots) { return ((slots - 3 * kZeroSlots) / 3) & ~63; }
 __host__ __device__ inline int fwd_cap2(int slots) { return ((slots - 2 * kZeroSlots) / 2) & ~63; }
@@ -168,7 +215,7 @@ k_fwd_brick(const float4 *__restrict__ featK, const float *__restrict__ proj, co
     const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
     if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
     const long long N = (long long)X * Y * Z;
-    const int HW = H * W, nqv = C >> 2, nq = nqv / ksplit, q0 = part * nq;       // nqv: quads per view (stride); nq: this block's, from q0
+    const int HW = H * W, nqv = (C + 3) >> 2, nq = (C >> 2) / ksplit, q0 = part * nq;   // nqv: quads per view (stride); nq: this block's WHOLE quads, from q0
 
     if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
     if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }

@@ -130,50 +130,6 @@ __device__ __forceinline__ float ws_softmax_safe(const float (&s)[V])
     }
 }
 
-// one voxel sampled straight from global memory (windows that do not fit LDS); `unscale` = ln 2 for a prescaled copy, else 1
-template <int METHOD, int VT, typename TO>
-__device__ __attribute__((noinline)) void ws_slow_voxel(const float4 *fk, TO *obase, const float (*proj)[12], const Coords coords, int b,   // by value: a reference would pin the kernel's copy in scratch
-                                                        long long N, unsigned vox, int nq, int nqv, int H, int W, int nv, float unscale)
-{
-    constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
-    const int HW = H * W;
-    float c0, c1, c2;
-    voxel_xyz(coords, b, N, vox, c0, c1, c2);
-    float w00[VT], w01[VT], w10[VT], w11[VT];
-    int o00[VT], o01[VT], o10[VT], o11[VT];
-#pragma unroll
-    for (int v = 0; v < VT; ++v) {
-        const Taps t = make_taps(proj[v], c0, c1, c2, H, W);
-        w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
-        const int base = ((v < nv ? v : 0) * nqv) * HW;                         // an absent view reads view 0's pixels (and discards them)
-        o00[v] = base + t.x0 * H + t.y0; o01[v] = base + t.x1 * H + t.y0; o10[v] = base + t.x0 * H + t.y1; o11[v] = base + t.x1 * H + t.y1;
-    }
-    for (int q = 0; q < nq; ++q) {
-        const float4 *src = fk + (long long)q * HW;
-        float s[4][VT];
-#pragma unroll
-        for (int v = 0; v < VT; ++v) {
-            const float4 a = src[o00[v]], bb = src[o01[v]], c = src[o10[v]], d = src[o11[v]];
-            s[0][v] = bilerp(a.x, bb.x, c.x, d.x, w00[v], w01[v], w10[v], w11[v]) * unscale;
-            s[1][v] = bilerp(a.y, bb.y, c.y, d.y, w00[v], w01[v], w10[v], w11[v]) * unscale;
-            s[2][v] = bilerp(a.z, bb.z, c.z, d.z, w00[v], w01[v], w10[v], w11[v]) * unscale;
-            s[3][v] = bilerp(a.w, bb.w, c.w, d.w, w00[v], w01[v], w10[v], w11[v]) * unscale;
-            if (v >= nv) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) s[i][v] = kAbsentReads ? kAbsentSample : 0.f;
-            }
-        }
-        TO *oq = obase + (long long)(q * 4) * N;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float r;
-            if constexpr (METHOD == AGG_MEAN) r = __fdiv_rn(aggregate<AGG_SUM, VT>(s[i]), (float)nv);
-            else r = aggregate<METHOD, VT>(s[i]);
-            (oq + i * N)[vox] = from_f32<TO>(r);
-        }
-    }
-}
-
 // ds_write_b32 at an LDS byte address + immediate offset (outside hipcc's lgkmcnt bookkeeping: see write_half)
 template <int OFF>
 __device__ __forceinline__ void lds_write_at(unsigned addr, float v)
@@ -187,7 +143,7 @@ struct WsBrick {
     const float4 *fk;            // staged features of this sample, quad 0
     TO *obase;                   // output of this sample, channel 0
     long long N;
-    int b, kx, ky, kz, nq, H, W, X, Y, Z, nv;
+    int b, kx, ky, kz, nq, nqv, C, H, W, X, Y, Z, nv;   // nq: whole channel quads (the fast loop's); nqv = (C + 3) / 4: the staged copy's quads per view
     unsigned chan_bytes, lds_base;
 };
 
@@ -201,8 +157,8 @@ __device__ __attribute__((noinline)) void ws_slow_units(const WsBrick<TO> B, con
         const int unit = u0 + u;
         const int vx = B.kx * 8 + 2 * (unit & 3) + dcol, vy = B.ky * 8 + (unit >> 2);
         if (vx < B.X && vy < B.Y && vz < B.Z)
-            ws_slow_voxel<METHOD, VT, TO>(B.fk, B.obase, proj, coords, B.b, B.N, (unsigned)(((long long)vx * B.Y + vy) * B.Z + vz), B.nq, B.nq, B.H, B.W,
-                                          B.nv, unscale);
+            fwd_global_voxel<METHOD, VT, TO>(B.fk, B.obase, proj, coords, B.b, B.N, (unsigned)(((long long)vx * B.Y + vy) * B.Z + vz), 0, B.nq, B.nqv, B.C,
+                                             B.H, B.W, B.nv, unscale);
     }
 }
 
@@ -237,7 +193,7 @@ __device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdSha
             int gx = ox + px, gy = oy + py;                                      // pad rows / columns past the window / outside the
             gx = gx < 0 ? 0 : (gx > B.W - 1 ? B.W - 1 : gx);                     // image: clamp -- those slots only meet zero weights
             gy = gy < 0 ? 0 : (gy > B.H - 1 ? B.H - 1 : gy);
-            go[rr] = (unsigned)((v * B.nq) * HW + gx * B.H + gy) * 16u;
+            go[rr] = (unsigned)((v * B.nqv) * HW + gx * B.H + gy) * 16u;
             ++n_m;
         }
     }
@@ -575,9 +531,9 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
     if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
     WsBrick<TO> B;
     B.N = (long long)X * Y * Z;
-    B.nq = C >> 2; B.H = H; B.W = W; B.X = X; B.Y = Y; B.Z = Z; B.nv = nv; B.b = b; B.kx = kx; B.ky = ky; B.kz = kz;
+    B.nq = C >> 2; B.nqv = (C + 3) >> 2; B.C = C; B.H = H; B.W = W; B.X = X; B.Y = Y; B.Z = Z; B.nv = nv; B.b = b; B.kx = kx; B.ky = ky; B.kz = kz;
     B.obase = out + (long long)b * C * B.N;
-    B.fk = featK + (long long)b * nv * B.nq * (H * W);
+    B.fk = featK + (long long)b * nv * B.nqv * (H * W);
     B.chan_bytes = (unsigned)(B.N * sizeof(TO));
     B.lds_base = (unsigned)(size_t)(lds_void_t *)smem;
 

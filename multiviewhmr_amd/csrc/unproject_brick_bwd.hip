@@ -50,8 +50,11 @@ constexpr int kAuxCmax = 12;       // BrickShared::aux word of the tap multiplic
 // Slow path of k_bwd_brick for one voxel: global float atomics per tap (bricks whose windows do not fit the LDS pool).
 template <int METHOD, int VT, typename TO>
 __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const TO *gobase, float *gk, const float (*proj)[12],
-                                                         float c0, float c1, float c2, unsigned vox, long long N, int nq, int H, int W, int nv)
+                                                         float c0, float c1, float c2, unsigned vox, long long N, int q_begin, int q_end, int nqv, int C, int H,
+                                                         int W, int nv)
 {
+    // channel quads q_begin .. q_end - 1 of the nqv = (C + 3) / 4 a view holds; channels below C only (C % 4 != 0: the last quad's missing
+    // channels have no grad_out)
     const int HW = H * W;
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
     float w00[VT], w01[VT], w10[VT], w11[VT];
@@ -62,10 +65,10 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
         w00[v] = t.w00; w01[v] = t.w01; w10[v] = t.w10; w11[v] = t.w11;
         const int x0 = t.rx0 < 0 ? 0 : t.rx0, y0 = t.ry0 < 0 ? 0 : t.ry0;
         const int x1 = t.rx0 + 1 > W - 1 ? W - 1 : t.rx0 + 1, y1 = t.ry0 + 1 > H - 1 ? H - 1 : t.ry0 + 1;
-        const int base = ((v < nv ? v : 0) * nq) * HW;                          // an absent view reads view 0's pixels (and discards them)
+        const int base = ((v < nv ? v : 0) * nqv) * HW;                         // an absent view reads view 0's pixels (and discards them)
         o00[v] = base + x0 * H + y0; o01[v] = base + x1 * H + y0; o10[v] = base + x0 * H + y1; o11[v] = base + x1 * H + y1;   // column-major copy
     }
-    for (int q = 0; q < nq; ++q) {
+    for (int q = q_begin; q < q_end; ++q) {
         const float4 *src = fk + (long long)q * HW;
         float *gq = gk + (long long)q * HW * 4;
         float s[4][VT];
@@ -83,6 +86,7 @@ __device__ __attribute__((noinline)) void bwd_brick_slow(const float4 *fk, const
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            if (q * 4 + i >= C) break;
             const float g = to_f32<TO>(gobase[(long long)(q * 4 + i) * N + vox]);
             float ds[VT];
             if constexpr (METHOD == AGG_MEAN) aggregate_grad<AGG_SUM, VT>(s[i], __fdiv_rn(g, (float)nv), ds);   // g / (real views), as autograd of mean(0)
@@ -123,7 +127,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     if (brick >= bricks_per_sample || b * bricks_per_sample >= total_blocks) return;
     const int kz = brick % nbz, ky = (brick / nbz) % nby, kx = brick / (nbz * nby);
     const long long N = (long long)X * Y * Z;
-    const int HW = H * W, nq = C >> 2;
+    const int HW = H * W, nq = C >> 2, nqv = (C + 3) >> 2;                       // nq: whole channel quads (the quad loop's); nqv: quads per view of the staged copy and the accumulator
 
     if (tid < VT * 12) sh->proj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
     if (tid < VT) { sh->bbox[tid][0] = 1 << 30; sh->bbox[tid][1] = 1 << 30; sh->bbox[tid][2] = -(1 << 30); sh->bbox[tid][3] = -(1 << 30); }
@@ -196,8 +200,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     constexpr int plane_floats = kZeroSlots + cap;
     int *const iplanes = reinterpret_cast<int *>(smem + NBUF * buf_bytes);
     const bool fits = used <= cap && nch[VT] <= MC * NW && max_stride + 2 <= kZeroSlots;
-    const float4 *const fk = featK + (long long)b * nv * nq * HW;
-    float *const gk = gradK + (long long)b * nv * nq * HW * 4;
+    const float4 *const fk = featK + (long long)b * nv * nqv * HW;
+    float *const gk = gradK + (long long)b * nv * nqv * HW * 4;
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
     const TO *const gobase = grad_out + (long long)b * C * N;
     const unsigned chan_bytes = (unsigned)(N * 4);
@@ -252,7 +256,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
                 const int Wt = H, Ht = W;                                        // transposed image (see the tap records)
                 const unsigned live = (px < bw && py < bh && gx >= 0 && gx < Wt && gy >= 0 && gy < Ht) ? 1u : 0u;
                 const int cx = gx < 0 ? 0 : (gx > Wt - 1 ? Wt - 1 : gx), cy = gy < 0 ? 0 : (gy > Ht - 1 ? Ht - 1 : gy);
-                g_off[r] = ((unsigned)((v * nq) * HW + cy * Wt + cx) * 16u) | (live ? 0u : 0x80000000u);
+                g_off[r] = ((unsigned)((v * nqv) * HW + cy * Wt + cx) * 16u) | (live ? 0u : 0x80000000u);
                 l_dst[r] = kZeroBytes + (s0 + (jj << 6)) * 16;
                 c_slot[r] = kZeroSlots + s0 + (jj << 6);
             }
@@ -328,8 +332,8 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
         const unsigned aux_base = (unsigned)(size_t)(lds_void_t *)sh->aux;
         const unsigned ch4 = 4u * (lane & 3);                                    // this lane's channel in the flush
         const unsigned long long gk_bits = (unsigned long long)(size_t)gk;
-        const int4v dgk = {uniform((int)(unsigned)gk_bits), uniform((int)((unsigned)(gk_bits >> 32) & 0xffffu)), (int)((unsigned)nv * nq * HW * 16u), 0x00020000};
-        const __amdgpu_buffer_rsrc_t rgk = __builtin_amdgcn_make_buffer_rsrc(gk, 0, (int)((unsigned)nv * nq * HW * 16u), 0x00020000);   // this sample's accumulator
+        const int4v dgk = {uniform((int)(unsigned)gk_bits), uniform((int)((unsigned)(gk_bits >> 32) & 0xffffu)), (int)((unsigned)nv * nqv * HW * 16u), 0x00020000};
+        const __amdgpu_buffer_rsrc_t rgk = __builtin_amdgcn_make_buffer_rsrc(gk, 0, (int)((unsigned)nv * nqv * HW * 16u), 0x00020000);   // this sample's accumulator
         float ds[4][VT], s[4][VT];
         auto resample = [&](int q) {                                             // samples of quad q from its window buffer
             const int boff = (q & (NBUF - 1)) * buf_bytes;
@@ -532,7 +536,7 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     } else {
         // ---- windows do not fit: scatter straight to the accumulator (its own function: keeps its registers -- 16 tap
         // offsets on top of the weights -- out of the fast path's allocation, which otherwise spills in the quad loop)
-        if (inside) bwd_brick_slow<METHOD, VT, TO>(fk, gobase, gk, sh->proj, c0, c1, c2, vox, N, nq, H, W, nv);
+        if (inside) bwd_brick_slow<METHOD, VT, TO>(fk, gobase, gk, sh->proj, c0, c1, c2, vox, N, 0, nq, nqv, C, H, W, nv);
     }
 }
 
@@ -549,7 +553,7 @@ k_quad_planar_to_planar(const float4 *__restrict__ src, TF *__restrict__ dst, in
     const long long bv = blockIdx.z;
     const int q = blockIdx.y, x0 = blockIdx.x * BW;
     const int cols = W - x0 < BW ? W - x0 : BW;
-    const float4 *s = src + ((bv * (C >> 2) + q) * W + x0) * (long long)H;
+    const float4 *s = src + ((bv * ((C + 3) >> 2) + q) * W + x0) * (long long)H;
     for (int i = threadIdx.x; i < cols * H; i += 512) {
         const float4 g = s[i];
         const int xl = i / H, y = i - xl * H;
@@ -559,8 +563,9 @@ k_quad_planar_to_planar(const float4 *__restrict__ src, TF *__restrict__ dst, in
     __syncthreads();
     TF *d = dst + (bv * C + q * 4) * (long long)H * W + x0;
     const int xl = threadIdx.x & (BW - 1);
+    const int nc = C - q * 4 < 4 ? C - q * 4 : 4;                                // C % 4 != 0: the last quad's missing channels are not written
     if (xl < cols)
-        for (int r = threadIdx.x / BW; r < 4 * H; r += 512 / BW) d[(long long)r * W + xl] = from_f32<TF>(tile[r * TS + xl]);   // r = channel * H + y
+        for (int r = threadIdx.x / BW; r < nc * H; r += 512 / BW) d[(long long)r * W + xl] = from_f32<TF>(tile[r * TS + xl]);   // r = channel * H + y
 }
 
 // band width of the gradient layout pass: 32 columns where 4 x H x 33 floats fit 64 KB of LDS (H <= 124), else 8
@@ -636,22 +641,77 @@ hipError_t launch_bt(const float4 *fk, const TO *go, const float *proj, const Co
 }
 }  // namespace
 
+// ---- C % 4 != 0: k_bwd_brick's quad loop runs the C / 4 whole channel quads; the last, partial quad goes per voxel through bwd_brick_slow
+// (float atomics into the accumulator: those 1 ... 3 channels' gradient is not bit-reproducible between runs), one thread per voxel, launched
+// behind the brick kernel.  (As a cold tail inside k_bwd_brick the same code would keep kernel arguments alive through the quad loop.)
+template <int METHOD, int VT, typename TO>
+__global__ void __launch_bounds__(256)
+k_bwd_tail(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, const float *__restrict__ proj, const Coords coords, float *__restrict__ gradK,
+           int C, int H, int W, long long N, int nv, Gate gate)
+{
+    if (gated_off(gate)) return;
+    __shared__ float sproj[VT][12];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid < VT * 12) sproj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
+    __syncthreads();
+    const long long n = (long long)blockIdx.x * 256 + tid;
+    if (n >= N) return;
+    const int nqv = (C + 3) >> 2;
+    const long long HW = (long long)H * W;
+    float c0, c1, c2;
+    voxel_xyz(coords, b, N, (unsigned)n, c0, c1, c2);
+    bwd_brick_slow<METHOD, VT, TO>(featK + (long long)b * nv * nqv * HW, grad_out + (long long)b * C * N, gradK + (long long)b * nv * nqv * HW * 4, sproj, c0, c1, c2,
+                                   (unsigned)n, N, C >> 2, nqv, nqv, C, H, W, nv);
+}
+
+namespace {
+template <int METHOD, typename TO>
+hipError_t launch_bwd_tail_views(const float4 *fk, const TO *go, const float *proj, const Coords &coords, float *gradK, const Problem &p, hipStream_t s)
+{
+    const dim3 grid((unsigned)((p.N + 255) / 256), (unsigned)p.B);
+    const Gate gate = make_gate(p, true);
+    switch (brick_view_slots(p.V)) {
+    case 2: hipLaunchKernelGGL((k_bwd_tail<METHOD, 2, TO>), grid, dim3(256), 0, s, fk, go, proj, coords, gradK, p.C, p.H, p.W, p.N, p.V, gate); break;
+    case 4: hipLaunchKernelGGL((k_bwd_tail<METHOD, 4, TO>), grid, dim3(256), 0, s, fk, go, proj, coords, gradK, p.C, p.H, p.W, p.N, p.V, gate); break;
+    case 8: hipLaunchKernelGGL((k_bwd_tail<METHOD, 8, TO>), grid, dim3(256), 0, s, fk, go, proj, coords, gradK, p.C, p.H, p.W, p.N, p.V, gate); break;
+    default: return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
+
+template <typename TO>
+hipError_t launch_bwd_tail(const float4 *fk, const TO *go, const float *proj, const Coords &coords, float *gradK, const Problem &p, hipStream_t s)
+{
+    switch (p.method) {
+    case AGG_SOFTMAX: return launch_bwd_tail_views<AGG_SOFTMAX, TO>(fk, go, proj, coords, gradK, p, s);
+    case AGG_SUM: return launch_bwd_tail_views<AGG_SUM, TO>(fk, go, proj, coords, gradK, p, s);
+    case AGG_MEAN: return launch_bwd_tail_views<AGG_MEAN, TO>(fk, go, proj, coords, gradK, p, s);
+    case AGG_MAX: return launch_bwd_tail_views<AGG_MAX, TO>(fk, go, proj, coords, gradK, p, s);
+    }
+    return hipErrorInvalidValue;
+}
+}  // namespace
+
 // featK: quad-planar features; gradK: zeroed fp32 quad-planar accumulator of the same shape
 hipError_t launch_bwd_brick(const void *featK, const void *grad_out, const float *proj, const Coords &coords, float *gradK, const Problem &p,
                             hipStream_t s)
 {
     if (!brick_bwd_supported(p)) return hipErrorNotSupported;
     const float4 *fk = static_cast<const float4 *>(featK);
-    if (p.out_bf16) return launch_bt<bf16_t>(fk, static_cast<const bf16_t *>(grad_out), proj, coords, gradK, p, s);
-    return p.out_f16 ? launch_bt<__half>(fk, static_cast<const __half *>(grad_out), proj, coords, gradK, p, s)
-                     : launch_bt<float>(fk, static_cast<const float *>(grad_out), proj, coords, gradK, p, s);
+    hipError_t e;
+    if (p.out_bf16) e = launch_bt<bf16_t>(fk, static_cast<const bf16_t *>(grad_out), proj, coords, gradK, p, s);
+    else e = p.out_f16 ? launch_bt<__half>(fk, static_cast<const __half *>(grad_out), proj, coords, gradK, p, s)
+                       : launch_bt<float>(fk, static_cast<const float *>(grad_out), proj, coords, gradK, p, s);
+    if (e != hipSuccess || !(p.C & 3)) return e;
+    if (p.out_bf16) return launch_bwd_tail<bf16_t>(fk, static_cast<const bf16_t *>(grad_out), proj, coords, gradK, p, s);   // the last, partial quad
+    return p.out_f16 ? launch_bwd_tail<__half>(fk, static_cast<const __half *>(grad_out), proj, coords, gradK, p, s)
+                     : launch_bwd_tail<float>(fk, static_cast<const float *>(grad_out), proj, coords, gradK, p, s);
 }
 
 hipError_t launch_quad_grad_to_planar(const float *gradK, void *dst, const Problem &p, hipStream_t s)
 {
-    if (p.C % 4) return hipErrorNotSupported;
     const int bw = grad_band(p);
-    const dim3 grid((p.W + bw - 1) / bw, p.C / 4, p.B * p.V);
+    const dim3 grid((p.W + bw - 1) / bw, p.C4 / 4, p.B * p.V);
     const size_t lds = (size_t)4 * p.H * (bw + 1) * sizeof(float);
     const float4 *g = (const float4 *)gradK;
     const Gate gate = make_gate(p, true);
@@ -669,9 +729,9 @@ bool brick_bwd_supported(const Problem &p)
 {
     if ((p.out_f16 && !p.feat_f16) || (p.out_bf16 && p.feat_f16)) return false;   // grad_out and the feature gradient each in their own storage type; these two pairings do not exist (capi: check_desc)
     if (p.V < 1 || p.V > 8) return false;
-    if (p.C % 4) return false;
-    if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
-    if ((long long)p.V * (p.C / 4) * p.H * p.W >= (1ll << 27)) return false;   // one sample's accumulator: 32-bit byte offsets (buffer atomics)
+    if (p.C < 4) return false;                                                    // r05: C % 4 != 0 -- whole quads in the quad loop, the rest per voxel
+    if ((long long)p.B * p.V * (p.C4 / 4) * p.H * p.W >= (1ll << 31)) return false;
+    if ((long long)p.V * (p.C4 / 4) * p.H * p.W >= (1ll << 27)) return false;   // one sample's accumulator: 32-bit byte offsets (buffer atomics)
     if (p.N >= (1ll << 28)) return false;
     if ((size_t)4 * p.H * 9 * sizeof(float) > 64 * 1024) return false;           // the gradient layout pass turns column bands through LDS (H <= 455)
     return true;

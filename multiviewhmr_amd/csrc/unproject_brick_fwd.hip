@@ -20,15 +20,16 @@ k_to_quad_planar_t(const TF *__restrict__ src, float4 *__restrict__ dst, int C, 
     const int x0 = (blockIdx.x % tiles_x) << 5, y0 = (blockIdx.x / tiles_x) << 5;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;                     // 8 rows per pass
     const TF *s = src + (bv * C + q * 4) * (long long)H * W;
+    const int nc = C - q * 4 < 4 ? C - q * 4 : 4;                                // the last quad of C % 4 != 0 channels: the missing ones are zeros
 #pragma unroll
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int y = y0 + ty + 8 * i, x = x0 + tx;
-            if (y < H && x < W) tile[c][ty + 8 * i][tx] = to_f32<TF>(s[(long long)c * H * W + (long long)y * W + x]) * scale;
+            if (y < H && x < W) tile[c][ty + 8 * i][tx] = c < nc ? to_f32<TF>(s[(long long)c * H * W + (long long)y * W + x]) * scale : 0.f;
         }
     __syncthreads();
-    float4 *d = dst + (bv * (C >> 2) + q) * (long long)H * W;
+    float4 *d = dst + (bv * ((C + 3) >> 2) + q) * (long long)H * W;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int xx = ty + 8 * i, y = y0 + tx, x = x0 + xx;                    // lanes run along y
@@ -51,11 +52,14 @@ k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, in
     const long long plane = (long long)H * W;
     const TF *s = src + (bv * C + q * 4) * plane + (long long)y0 * W;
     const int n = rows * W;
+    const int nc = C - q * 4 < 4 ? C - q * 4 : 4;                                // the last quad of C % 4 != 0 channels: the missing ones are zeros
+    for (int c = nc; c < 4; ++c)
+        for (int i = threadIdx.x; i < n; i += 512) band[(c * 32 + i / W) * ldw + i % W] = 0.f;
     // vector loads only from an aligned base (src_aligned: 16 B for fp32, 8 B for fp16 -- a slice of a flat buffer or a raw C-ABI
     // pointer may start anywhere: ADVICE r03)
     if (sizeof(TF) == 4 && (W & 3) == 0 && (plane & 3) == 0 && src_aligned) {
         // 16-B loads: 4 consecutive x of one row (W % 4 == 0 keeps them inside a row and aligned)
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < nc; ++c)
             for (int i = threadIdx.x * 4; i < n; i += 512 * 4) {
                 const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(s) + (long long)c * plane + i);
                 const int y = i / W, x = i - y * W;
@@ -64,7 +68,7 @@ k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, in
             }
     } else if (sizeof(TF) == 2 && (W & 3) == 0 && (plane & 3) == 0 && src_aligned) {
         // fp16 features: 8-B loads of 4 consecutive x (2-B loads ran this pass at 3.8 TB/s instead of the fp32 form's 5.9)
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < nc; ++c)
             for (int i = threadIdx.x * 4; i < n; i += 512 * 4) {
                 const f32x4 t = Vec4<__half>::load(reinterpret_cast<const __half *>(s) + (long long)c * plane + i);
                 const int y = i / W, x = i - y * W;
@@ -72,14 +76,14 @@ k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, in
                 b[0] = t.v[0]; b[1] = t.v[1]; b[2] = t.v[2]; b[3] = t.v[3];
             }
     } else {
-        for (int c = 0; c < 4; ++c)
+        for (int c = 0; c < nc; ++c)
             for (int i = threadIdx.x; i < n; i += 512) {
                 const int y = i / W, x = i - y * W;
                 band[(c * 32 + y) * ldw + x] = to_f32<TF>(s[(long long)c * plane + i]);
             }
     }
     __syncthreads();
-    float4 *d = dst + (bv * (C >> 2) + q) * plane;
+    float4 *d = dst + (bv * ((C + 3) >> 2) + q) * plane;
     const int ty = threadIdx.x & 31;
     if (ty < rows)
         for (int x = threadIdx.x >> 5; x < W; x += 16)
@@ -89,18 +93,17 @@ k_to_quad_planar_t_band(const TF *__restrict__ src, float4 *__restrict__ dst, in
 
 hipError_t launch_to_quad_planar_t(const void *src, void *dst, const Problem &p, hipStream_t s, bool brick_side)
 {
-    if (p.C % 4) return hipErrorNotSupported;
     const float scale = p.feat_log2e ? kLog2e : 1.f;
     const Gate gate = make_gate(p, brick_side);
     const size_t band_bytes = (size_t)4 * 32 * (p.W | 1) * sizeof(float);
     if (band_bytes <= 64 * 1024) {                                               // 2+ blocks per CU
-        const dim3 grid((p.H + 31) / 32, p.C / 4, p.B * p.V);
+        const dim3 grid((p.H + 31) / 32, p.C4 / 4, p.B * p.V);
         const int aligned = (reinterpret_cast<uintptr_t>(src) % (p.feat_f16 ? 8 : 16)) == 0;
         if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t_band<__half>, grid, dim3(512), band_bytes, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, aligned, scale, gate);
         else hipLaunchKernelGGL(k_to_quad_planar_t_band<float>, grid, dim3(512), band_bytes, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, aligned, scale, gate);
         return hipGetLastError();
     }
-    const dim3 grid(((p.W + 31) / 32) * ((p.H + 31) / 32), p.C / 4, p.B * p.V);
+    const dim3 grid(((p.W + 31) / 32) * ((p.H + 31) / 32), p.C4 / 4, p.B * p.V);
     if (p.feat_f16) hipLaunchKernelGGL(k_to_quad_planar_t<__half>, grid, dim3(256), 0, s, (const __half *)src, (float4 *)dst, p.C, p.H, p.W, scale, gate);
     else hipLaunchKernelGGL(k_to_quad_planar_t<float>, grid, dim3(256), 0, s, (const float *)src, (float4 *)dst, p.C, p.H, p.W, scale, gate);
     return hipGetLastError();
@@ -145,7 +148,7 @@ hipError_t launch_channels_last_to_quad_planar_t(const void *src, void *dst, con
 
 size_t brick_workspace_bytes(const Problem &p)
 {
-    const size_t n = (size_t)p.B * p.V * p.C * p.H * p.W * sizeof(float);
+    const size_t n = (size_t)p.B * p.V * p.C4 * p.H * p.W * sizeof(float);            // (C + 3) / 4 quads per view: the last one zero-padded
     return (n + 255) / 256 * 256;
 }
 
@@ -165,10 +168,10 @@ bool brick_fwd_grouped(const Problem &p) { return !MVHMR_NO_GROUPS && p.V > 4; }
 bool brick_fwd_supported(const Problem &p)
 {
     if (p.V < 1 || p.V > 8) return false;                                 // 1 / 3 / 5 / 6 / 7 views: the next larger kernel, missing views absent
-    if (p.C % 4) return false;
+    if (p.C < 4) return false;                                            // r05: C % 4 != 0 -- the whole quads through the fast loop, the rest per voxel (fwd_brick_tail)
     // r04: any X, Y, Z -- bricks that stick out of the volume idle their outside lanes.  16-bit volumes store z pairs: Z even.
     if ((p.out_f16 || p.out_bf16) && (p.Z & 1)) return false;
-    if ((long long)p.B * p.V * (p.C / 4) * p.H * p.W >= (1ll << 31)) return false;
+    if ((long long)p.B * p.V * (p.C4 / 4) * p.H * p.W >= (1ll << 31)) return false;
     if (p.N >= (1ll << 28)) return false;                                 // 32-bit byte offsets inside one quad of the output
     return true;
 }
@@ -272,16 +275,69 @@ extern template hipError_t launch_fwd_method<AGG_SUM>(const void *, const float 
 extern template hipError_t launch_fwd_method<AGG_MEAN>(const void *, const float *, const Coords &, void *, const Problem &, int, hipStream_t);
 extern template hipError_t launch_fwd_method<AGG_MAX>(const void *, const float *, const Coords &, void *, const Problem &, int, hipStream_t);
 
+// ---- C % 4 != 0: the brick kernels' loops run the C / 4 whole channel quads; the last, partial quad of the staged copy (its missing
+// channels are zeros) is sampled per voxel from global memory by this kernel, launched behind them -- one thread per voxel, the 1 ... 3
+// channels of the quad, the gather kernels' speed for 1 of (C + 3) / 4 quads.  (Inside the brick kernels the same code as a cold tail
+// cost their hot loops registers: spills in k_fwd_brick's quad loop, which the build gate refuses.)
+template <int METHOD, int VT, typename TO>
+__global__ void __launch_bounds__(256)
+k_fwd_tail(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords, TO *__restrict__ out, int C, int H, int W, long long N,
+           int nv, float unscale, Gate gate)
+{
+    if (gated_off(gate)) return;
+    __shared__ float sproj[VT][12];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    if (tid < VT * 12) sproj[tid / 12][tid % 12] = tid < nv * 12 ? proj[((long long)b * nv) * 12 + tid] : 0.f;
+    __syncthreads();
+    const long long n = (long long)blockIdx.x * 256 + tid;
+    if (n >= N) return;
+    const int nqv = (C + 3) >> 2;
+    fwd_global_voxel<METHOD, VT, TO>(featK + (long long)b * nv * nqv * ((long long)H * W), out + (long long)b * C * N, sproj, coords, b, N, (unsigned)n, C >> 2, nqv,
+                                     nqv, C, H, W, nv, unscale);
+}
+
+template <int METHOD, typename TO>
+static hipError_t launch_fwd_tail_views(const float4 *featK, const float *proj, const Coords &coords, TO *out, const Problem &p, hipStream_t s)
+{
+    const dim3 grid((unsigned)((p.N + 255) / 256), (unsigned)p.B);
+    const float unscale = p.feat_log2e ? kLn2 : 1.f;
+    const Gate gate = make_gate(p, true);
+    switch (brick_view_slots(p.V)) {
+    case 2: hipLaunchKernelGGL((k_fwd_tail<METHOD, 2, TO>), grid, dim3(256), 0, s, featK, proj, coords, out, p.C, p.H, p.W, p.N, p.V, unscale, gate); break;
+    case 4: hipLaunchKernelGGL((k_fwd_tail<METHOD, 4, TO>), grid, dim3(256), 0, s, featK, proj, coords, out, p.C, p.H, p.W, p.N, p.V, unscale, gate); break;
+    case 8: hipLaunchKernelGGL((k_fwd_tail<METHOD, 8, TO>), grid, dim3(256), 0, s, featK, proj, coords, out, p.C, p.H, p.W, p.N, p.V, unscale, gate); break;
+    default: return hipErrorNotSupported;
+    }
+    return hipGetLastError();
+}
+
+template <int METHOD>
+static hipError_t launch_fwd_tail(const void *featK, const float *proj, const Coords &coords, void *out, const Problem &p, hipStream_t s)
+{
+    const float4 *fk = static_cast<const float4 *>(featK);
+    return p.out_f16    ? launch_fwd_tail_views<METHOD, __half>(fk, proj, coords, (__half *)out, p, s)
+           : p.out_bf16 ? launch_fwd_tail_views<METHOD, bf16_t>(fk, proj, coords, (bf16_t *)out, p, s)
+                        : launch_fwd_tail_views<METHOD, float>(fk, proj, coords, (float *)out, p, s);
+}
+
 // featK: column-major quad-planar fp32 copy of the features (launch_to_quad_planar_t)
 hipError_t launch_fwd_brick(const void *featK, const float *proj, const Coords &coords, void *out, const Problem &p, hipStream_t s)
 {
     if (!brick_fwd_supported(p)) return hipErrorNotSupported;
     const int nvox = brick_fwd_nvox(p);
+    hipError_t e = hipErrorInvalidValue;
     switch (p.method) {
-    case AGG_SOFTMAX: return launch_fwd_method<AGG_SOFTMAX>(featK, proj, coords, out, p, nvox, s);
-    case AGG_SUM: return launch_fwd_method<AGG_SUM>(featK, proj, coords, out, p, nvox, s);
-    case AGG_MEAN: return launch_fwd_method<AGG_MEAN>(featK, proj, coords, out, p, nvox, s);
-    case AGG_MAX: return launch_fwd_method<AGG_MAX>(featK, proj, coords, out, p, nvox, s);
+    case AGG_SOFTMAX: e = launch_fwd_method<AGG_SOFTMAX>(featK, proj, coords, out, p, nvox, s); break;
+    case AGG_SUM: e = launch_fwd_method<AGG_SUM>(featK, proj, coords, out, p, nvox, s); break;
+    case AGG_MEAN: e = launch_fwd_method<AGG_MEAN>(featK, proj, coords, out, p, nvox, s); break;
+    case AGG_MAX: e = launch_fwd_method<AGG_MAX>(featK, proj, coords, out, p, nvox, s); break;
+    }
+    if (e != hipSuccess || !(p.C & 3)) return e;
+    switch (p.method) {                                                          // the last, partial quad
+    case AGG_SOFTMAX: return launch_fwd_tail<AGG_SOFTMAX>(featK, proj, coords, out, p, s);
+    case AGG_SUM: return launch_fwd_tail<AGG_SUM>(featK, proj, coords, out, p, s);
+    case AGG_MEAN: return launch_fwd_tail<AGG_MEAN>(featK, proj, coords, out, p, s);
+    case AGG_MAX: return launch_fwd_tail<AGG_MAX>(featK, proj, coords, out, p, s);
     }
     return hipErrorInvalidValue;
 }

@@ -29,6 +29,7 @@ def run(seed=1, cases=60, big=False, dtype="f32", verbose=True):
             H, W = int(rng.integers(60, 220)), int(rng.integers(60, 220))
             X, Y, Z = int(rng.choice([8, 16])), int(rng.choice([8, 12, 16])), int(rng.choice([32, 64]))
             C = int(rng.choice([4, 8]))
+        if seed >= 500: C = int(rng.choice([5, 6, 7, 9, 10, 13, 22, 35]))            # r05: C % 4 != 0 on the brick kernels (whole quads in their loops, the rest through k_fwd_tail / k_bwd_tail)
         B = int(rng.integers(1, 3))
         # r05: the shapes above all lie below AUTO's brick threshold (B * X * Y * Z >= 196 608 voxels), so `auto` only ever ran
         # the gather kernels.  One case per seed is batched up to the threshold (the device-side gate then decides), and one to >= 256

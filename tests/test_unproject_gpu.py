@@ -27,10 +27,11 @@ def _dev(d, key, gpu, dtype=torch.float32):
 
 def _brick_ok(f, c):
     """shapes the brick forward takes (r04): 2 ... 8 views (3 / 5 / 6 / 7 run the next larger kernel with the missing views absent),
-    C % 4 == 0, ANY volume (bricks that stick out idle their outside lanes); 16-bit volumes store z pairs and need an even Z"""
+    C >= 4 (r05: C % 4 != 0 -- the last, partial quad per voxel behind the brick kernel), ANY volume (bricks that stick out idle their
+    outside lanes); 16-bit volumes store z pairs and need an even Z"""
     Z = c.shape[3]
     V = f.shape[1]
-    return 1 <= V <= 8 and f.shape[2] % 4 == 0 and (f.dtype == torch.float32 or Z % 2 == 0)
+    return 1 <= V <= 8 and f.shape[2] >= 4 and (f.dtype == torch.float32 or Z % 2 == 0)
 
 
 def _bound(ref):
@@ -246,6 +247,51 @@ def test_brick_backward_vs_oracle(shape, mode, gpu):
     gref = cport.backward(go, feats, proj, coords, mode)
     record_err("brick bwd %s V%d C%d %dx%d vol%s" % (mode, shape["V"], shape["C"], shape["H"], shape["W"], shape["vol"]),
                _err(f.grad.cpu().numpy(), gref), _bound(gref))
+
+
+@pytest.mark.parametrize("shape", [
+    dict(B=2, V=4, C=6, H=24, W=24, vol=(8, 8, 32)),          # k_fwd_brick / k_bwd_brick: one whole quad + 2 channels
+    dict(B=1, V=4, C=13, H=32, W=40, vol=(12, 20, 40)),       # ragged volume, non-square maps, 3 whole quads + 1 channel
+    dict(B=1, V=8, C=7, H=24, W=24, vol=(6, 10, 33)),         # 8 views (view groups / 8 x 4 x 16 bricks), 1 quad + 3 channels
+    dict(B=2, V=3, C=10, H=24, W=24, vol=(8, 8, 32)),         # an absent view in the partial quad as well
+    dict(B=1, V=4, C=70, H=48, W=48, vol=(32, 32, 32)),       # 17 whole quads: the channel split of small launches leaves the partial quad to the tail
+    dict(B=9, V=4, C=6, H=40, W=56, vol=(20, 36, 44)),        # >= 256 bricks: k_fwd_ws (prescaled copy for the softmax: the tail undoes the scale too)
+    dict(B=1, V=4, C=6, H=320, W=320, vol=(8, 8, 32)),        # windows overflow: whole quads through the in-kernel path, the partial one through the tail
+])
+@pytest.mark.parametrize("mode", MODES)
+def test_brick_kernels_take_channel_counts_that_are_not_multiples_of_four(shape, mode, gpu):
+    """round 5: C % 4 != 0 no longer falls to the gather kernels.  The staged copy holds (C + 3) / 4 quads per view (the
+    last one zero-padded by the layout pass), the brick kernels' loops run the C / 4 whole quads, and k_fwd_tail / k_bwd_tail do the last
+    1 ... 3 channels per voxel from global memory (the backward's with float atomics)"""
+    feats, proj, coords = _ring_problem(seed=91 + MODES.index(mode), **shape)
+    f = torch.from_numpy(feats).to(gpu).requires_grad_(True)
+    p, c = torch.from_numpy(proj).to(gpu), torch.from_numpy(coords).to(gpu)
+    d = aggregation._make_desc(f, tuple(c.shape[1:4]), _capi.AGG[mode], torch.float32, _capi.LAYOUT_BVCHW, _capi.VARIANT["brick"])
+    assert _capi.lib().mvhmr_unproject_forward_kernel_name(ctypes.byref(d)) in (b"k_fwd_brick", b"k_fwd_brick_groups", b"k_fwd_ws")
+    assert _capi.lib().mvhmr_unproject_backward_supported(ctypes.byref(d)) == 1
+    out = aggregation.unprojection(f, p, c, aggregation_method=mode, variant="brick")
+    ref = cport.forward(feats, proj, coords, mode)
+    name = "C %% 4 != 0: %s V%d C%d %dx%d vol%s" % (mode, shape["V"], shape["C"], shape["H"], shape["W"], shape["vol"])
+    record_err(name + " fwd", _err(out.detach().cpu().numpy(), ref), TOL)
+    go = np.random.default_rng(8).standard_normal(tuple(out.shape), dtype=np.float32)
+    out.backward(torch.from_numpy(go).to(gpu))
+    gref = cport.backward(go, feats, proj, coords, mode)
+    record_err(name + " bwd", _err(f.grad.cpu().numpy(), gref), _bound(gref))
+    # the whole quads are what they are at C rounded down: bit for bit the same kernels on the same data
+    c4 = shape["C"] // 4 * 4
+    out4 = aggregation.unprojection(f.detach()[:, :, :c4].contiguous(), p, c, aggregation_method=mode, variant="brick")
+    if mode != "softmax" or _capi.lib().mvhmr_unproject_forward_kernel_name(ctypes.byref(d)) != b"k_fwd_ws":
+        assert torch.equal(out.detach()[:, :c4], out4)
+    gat = aggregation.unprojection(f.detach(), p, c, aggregation_method=mode, variant="gather")
+    record_err(name + " vs gather", float((out.detach() - gat).abs().max()), 4e-6)
+    auto = aggregation.unprojection(f.detach(), p, c, aggregation_method=mode, variant="auto")
+    record_err(name + " auto", _err(auto.cpu().numpy(), ref), TOL)
+    if f.shape[3] < 300 and c.shape[3] % 2 == 0:                                   # 16-bit volumes (even Z): fp32 features -> bf16 volume
+        ob = aggregation.unprojection(f.detach(), p, c, aggregation_method=mode, variant="brick", out_dtype=torch.bfloat16)
+        db = aggregation._make_desc(f, tuple(c.shape[1:4]), _capi.AGG[mode], torch.bfloat16, _capi.LAYOUT_BVCHW, _capi.VARIANT["brick"])
+        same_kernel = _capi.lib().mvhmr_unproject_forward_kernel_name(ctypes.byref(db)) == _capi.lib().mvhmr_unproject_forward_kernel_name(ctypes.byref(d))
+        if same_kernel or mode != "softmax": assert torch.equal(ob, out.detach().to(torch.bfloat16))      # (k_fwd_ws needs Z % 8 == 0 for a 16-bit volume; its softmax differs from k_fwd_brick's by ~1e-7)
+        else: record_err(name + " bf16 volume", float((ob.float() - out.detach()).abs().max()), 2.0 ** -8 * max(1.0, float(out.detach().abs().max())))
 
 
 def test_random_geometries_through_the_gate(gpu):
