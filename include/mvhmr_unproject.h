@@ -68,9 +68,11 @@ typedef enum mvhmr_layout_t {
     MVHMR_LAYOUT_QUAD = 2,  /* (B,V,C/4,Wf,Hf,4) fp32 whatever feat_dtype -- column-major "quad-planar": a pixel's 4 channels
                                are 16 contiguous bytes and a pixel COLUMN is one contiguous run, which is what the brick
                                forward stages into LDS (tall narrow tap windows); produced by mvhmr_convert_features and by
-                               mvhmr_conv1x1_to_quad (C % 4 == 0).  Forward and backward accept it; the backward then writes
+                               mvhmr_conv1x1_to_quad.  C % 4 != 0 (round 5): (C + 3) / 4 quads per view, the last one zero-padded
+                               by mvhmr_convert_features; brick kernels only (their loops run the whole quads, the last 1 ... 3
+                               channels go per voxel).  Forward and backward accept it; the backward then writes
                                grad_features PLANAR (B,V,C,Hf,Wf).  With MVHMR_VARIANT_AUTO the geometry gate decides on the
-                               device as for planar input (the gather side converts the copy to channels-last first) */
+                               device as for planar input (the gather side converts the copy to channels-last first: C % 4 == 0) */
     MVHMR_LAYOUT_QUAD_LOG2E = 3 /* the same copy with every value multiplied by log2(e), FORWARD ONLY: what the wave-specialised softmax
                                forward stages (3 / 4 views, fp32 volume, launches of >= 256 bricks): its exponentials are then exp2 of
                                a plain difference and ln 2 is folded into the final multiply (<= 2e-7 relative to the unscaled

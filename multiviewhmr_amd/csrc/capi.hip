@@ -85,8 +85,9 @@ int check_desc(const mvhmr_unproject_desc *d, Problem *p)
     p->out_bf16 = d->out_dtype == MVHMR_BF16;
     if ((long long)p->H * p->W * p->C4 >= (1ll << 31))
         return fail(MVHMR_ERR_UNSUPPORTED, "one feature map (Hf*Wf*C = %lld elements) exceeds 32-bit tap offsets", (long long)p->H * p->W * p->C4);
-    if (d->feat_layout != MVHMR_LAYOUT_BVCHW && p->C4 != p->C)
-        return fail(MVHMR_ERR_UNSUPPORTED, "channels-last / quad-planar features need C %% 4 == 0 (C = %d)", p->C);
+    if (d->feat_layout == MVHMR_LAYOUT_BVHWC && p->C4 != p->C)
+        return fail(MVHMR_ERR_UNSUPPORTED, "channels-last features need C %% 4 == 0 (C = %d)", p->C);
+    // (quad-planar copies hold (C + 3) / 4 quads per view, the last one zero-padded: any C the brick kernels take)
     return MVHMR_OK;
 }
 
@@ -553,7 +554,7 @@ size_t mvhmr_feature_layout_bytes(const mvhmr_unproject_desc *desc, int dst_layo
     d.feat_layout = MVHMR_LAYOUT_BVCHW;
     if (check_desc(&d, &p) != MVHMR_OK) return 0;
     if (dst_layout == MVHMR_LAYOUT_BVHWC) return featT_bytes(p);
-    if ((dst_layout == MVHMR_LAYOUT_QUAD || dst_layout == MVHMR_LAYOUT_QUAD_LOG2E) && p.C4 == p.C) return brick_workspace_bytes(p);   // always fp32, whatever the storage type
+    if (dst_layout == MVHMR_LAYOUT_QUAD || dst_layout == MVHMR_LAYOUT_QUAD_LOG2E) return brick_workspace_bytes(p);   // always fp32, whatever the storage type; (C + 3) / 4 quads per view
     return 0;
 }
 

@@ -286,6 +286,22 @@ def test_brick_kernels_take_channel_counts_that_are_not_multiples_of_four(shape,
     record_err(name + " vs gather", float((out.detach() - gat).abs().max()), 4e-6)
     auto = aggregation.unprojection(f.detach(), p, c, aggregation_method=mode, variant="auto")
     record_err(name + " auto", _err(auto.cpu().numpy(), ref), TOL)
+    # a caller-held quad-planar copy ((C + 3) / 4 quads per view, the last one zero-padded by mvhmr_convert_features): the same volume
+    L, vp = _capi.lib(), ctypes.c_void_p
+    stream = vp(torch.cuda.current_stream(gpu).cuda_stream)
+    lay = L.mvhmr_preferred_layout(ctypes.byref(d))
+    nb = L.mvhmr_feature_layout_bytes(ctypes.byref(d), lay)
+    B_, V_, C_, H_, W_ = f.shape
+    assert nb >= B_ * V_ * ((C_ + 3) // 4) * H_ * W_ * 16
+    quad = torch.empty(nb // 4, device=gpu)
+    _capi.check(L.mvhmr_convert_features(ctypes.byref(d), vp(f.data_ptr()), lay, vp(quad.data_ptr()), stream))
+    dq = _capi.Desc.from_buffer_copy(d)
+    dq.feat_layout = lay
+    outq = torch.empty_like(out.detach())
+    wsb = L.mvhmr_unproject_forward_workspace_bytes(ctypes.byref(dq))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=gpu)
+    _capi.check(L.mvhmr_unproject_forward(ctypes.byref(dq), vp(quad.data_ptr()), vp(p.data_ptr()), vp(c.data_ptr()), vp(outq.data_ptr()), vp(ws.data_ptr()), wsb, stream))
+    assert torch.equal(outq, out.detach())
     if f.shape[3] < 300 and c.shape[3] % 2 == 0:                                   # 16-bit volumes (even Z): fp32 features -> bf16 volume
         ob = aggregation.unprojection(f.detach(), p, c, aggregation_method=mode, variant="brick", out_dtype=torch.bfloat16)
         db = aggregation._make_desc(f, tuple(c.shape[1:4]), _capi.AGG[mode], torch.bfloat16, _capi.LAYOUT_BVCHW, _capi.VARIANT["brick"])
