@@ -729,7 +729,7 @@ bool brick_bwd_supported(const Problem &p)
 {
     if ((p.out_f16 && !p.feat_f16) || (p.out_bf16 && p.feat_f16)) return false;   // grad_out and the feature gradient each in their own storage type; these two pairings do not exist (capi: check_desc)
     if (p.V < 1 || p.V > 8) return false;
-    if (p.C < 4) return false;                                                    // r05: C % 4 != 0 -- whole quads in the quad loop, the rest per voxel
+    if (p.C < 4 || ((p.C & 3) && p.B > 65535)) return false;                      // r05: C % 4 != 0 -- whole quads in the quad loop, the rest per voxel (k_bwd_tail: grid.y = B)
     if ((long long)p.B * p.V * (p.C4 / 4) * p.H * p.W >= (1ll << 31)) return false;
     if ((long long)p.V * (p.C4 / 4) * p.H * p.W >= (1ll << 27)) return false;   // one sample's accumulator: 32-bit byte offsets (buffer atomics)
     if (p.N >= (1ll << 28)) return false;

@@ -168,7 +168,7 @@ bool brick_fwd_grouped(const Problem &p) { return !MVHMR_NO_GROUPS && p.V > 4; }
 bool brick_fwd_supported(const Problem &p)
 {
     if (p.V < 1 || p.V > 8) return false;                                 // 1 / 3 / 5 / 6 / 7 views: the next larger kernel, missing views absent
-    if (p.C < 4) return false;                                            // r05: C % 4 != 0 -- the whole quads through the fast loop, the rest per voxel (fwd_brick_tail)
+    if (p.C < 4 || ((p.C & 3) && p.B > 65535)) return false;              // r05: C % 4 != 0 -- the whole quads through the fast loops, the rest per voxel (k_fwd_tail: grid.y = B)
     // r04: any X, Y, Z -- bricks that stick out of the volume idle their outside lanes.  16-bit volumes store z pairs: Z even.
     if ((p.out_f16 || p.out_bf16) && (p.Z & 1)) return false;
     if ((long long)p.B * p.V * (p.C4 / 4) * p.H * p.W >= (1ll << 31)) return false;
