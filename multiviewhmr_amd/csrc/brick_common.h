@@ -14,6 +14,20 @@ constexpr int brick_chunks_per_wave(int nt) { return nt >= 1024 ? kMaxChunks : 2
 // an absent view has no camera and no window; where the aggregate needs it out of the way (softmax, max) its samples read
 // kAbsentSample from slot kAbsentSlot of the always-zero head of every LDS ring buffer (its neighbours stay zero).
 constexpr int brick_view_slots(int v) { return v <= 2 ? 2 : v <= 4 ? 4 : 8; }
+
+// the four tiles of a sample's bricks (block order of k_fwd_ws, and of k_bwd_brick: see there): which two axes are halved and the tile's extents in bricks
+struct BrickTiles { int hx, hy, hz, share; bool split_x, split_y, split_z; };
+__host__ __device__ inline BrickTiles brick_tiles(int nbx, int nby, int nbz)
+{
+    BrickTiles t;
+    t.split_z = nbz >= 2;
+    t.split_x = t.split_z ? nbx > nby : true;
+    t.split_y = t.split_z ? !t.split_x : true;
+    t.hx = t.split_x ? (nbx + 1) / 2 : nbx; t.hy = t.split_y ? (nby + 1) / 2 : nby; t.hz = t.split_z ? (nbz + 1) / 2 : nbz;
+    t.share = t.hx * t.hy * t.hz;
+    return t;
+}
+
 constexpr int kAbsentSlot = 64;
 constexpr float kAbsentSample = -3.4028234663852886e38f;                        // -FLT_MAX: exp(that - m) = 0, 0 * that = -0, never a maximum
 constexpr int kZeroSlots = 128;    // always-zero 16-B slots at the head of every ring buffer (row stride <= 126)

@@ -518,17 +518,25 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
     FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + kWsLdsBytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
 
-    // XCD-aware order as in k_fwd_brick (speed only): blocks i, i + 8, ... share an XCD under round-robin dispatch; all eight XCDs work
-    // on the same sample, each on a compact tile of brick columns (all z)
+    // XCD-aware order (speed only): blocks i, i + 8, ... share an XCD under round-robin dispatch.  Four tiles per sample -- half of z (when
+    // there are two bricks along z) x half of the longer of x / y, else half of x x half of y --, XCDs 0-3 on sample 2 p, XCDs 4-7 on sample
+    // 2 p + 1: the 32 bricks an XCD works on at a time then share most of their windows, and a feature plane is fetched by at most four L2s.
+    // Memory-side reads of the north star: 2.8 GB instead of the 4.5 GB of eight tiles per sample over all eight XCDs (1.3 GB are compulsory;
+    // profiles/r05_fwd_ablations.txt G) -- at the same kernel time: those re-reads hit the Infinity Cache and cost little energy.
     const int nbx = bricks_per_sample / (nby * nbz);
-    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
-    const int tw = (nbx + tiles_x - 1) / tiles_x, th = (nby + tiles_y - 1) / tiles_y;
-    const int share = tw * th * nbz;
+    const BrickTiles T = brick_tiles(nbx, nby, nbz);
     const int bid = (int)blockIdx.x, xcd = bid & 7, j = bid >> 3;
-    const int b = j / share, r = j % share;
-    const int kz = r % nbz, cy = (r / nbz) % th, cx = r / (nbz * th);
-    const int kx = (xcd % tiles_x) * tw + cx, ky = (xcd / tiles_x) * th + cy;
-    if (kx >= nbx || ky >= nby || b * bricks_per_sample >= total_blocks) return;
+    const int pj = j / T.share, r = j % T.share, tile = xcd & 3;
+    int b = 2 * pj + (xcd >> 2);
+    if ((2 * pj + 1) * bricks_per_sample >= total_blocks) {                      // an odd batch's last sample: all eight XCDs on it, XCD t and t + 4
+        b = 2 * pj;                                                              // take alternate bricks of tile t
+        if ((r & 1) != (xcd >> 2)) return;
+    }
+    const int cz = r % T.hz, cy = (r / T.hz) % T.hy, cx = r / (T.hz * T.hy);
+    const int kz = T.split_z ? (tile >> 1) * T.hz + cz : cz;
+    const int kx = T.split_x ? (T.split_z ? tile & 1 : tile >> 1) * T.hx + cx : cx;
+    const int ky = T.split_y ? (tile & 1) * T.hy + cy : cy;
+    if (kx >= nbx || ky >= nby || kz >= nbz || b * bricks_per_sample >= total_blocks) return;
     WsBrick<TO> B;
     B.N = (long long)X * Y * Z;
     B.nq = C >> 2; B.nqv = (C + 3) >> 2; B.C = C; B.H = H; B.W = W; B.X = X; B.Y = Y; B.Z = Z; B.nv = nv; B.b = b; B.kx = kx; B.ky = ky; B.kz = kz;
@@ -576,8 +584,7 @@ hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const 
     auto kern = k_fwd_ws<METHOD, VT, TO, PRE, CFG>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
-    const int tiles_x = nbx >= nby ? 4 : 2, tiles_y = 8 / tiles_x;
-    const int grid = ((nbx + tiles_x - 1) / tiles_x) * ((nby + tiles_y - 1) / tiles_y) * nbz * 8 * p.B;   // tile work items x 8 XCDs x samples
+    const int grid = 8 * brick_tiles(nbx, nby, nbz).share * ((p.B + 1) / 2);          // 8 XCDs x bricks of a tile x pairs of samples
     hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG == 0 ? 768 : 1024), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, total, p.V,
                        make_gate(p, true));
     return hipGetLastError();

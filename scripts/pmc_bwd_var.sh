@@ -17,6 +17,8 @@ for p in $passes; do
     b) pass b SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_WR || exit 1;;
     c) pass c SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_WAIT_INST_LDS SQ_LDS_UNALIGNED_STALL SQ_INST_LEVEL_LDS || exit 1;;
     e) pass e GRBM_GUI_ACTIVE || exit 1;;
+    h) pass h FETCH_SIZE || exit 1;;
+    i) pass i WRITE_SIZE || exit 1;;
     t1) pass t1 TCP_GATE_EN1 TCP_GATE_EN2 TCP_PENDING_STALL_CYCLES TCP_TOTAL_ACCESSES || exit 1;;
     t2) pass t2 TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_TCC_ATOMIC_WITHOUT_RET_REQ TCP_TA_TCP_STATE_READ || exit 1;;
     d) pass d SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_VMEM_RD SQ_CYCLES || exit 1;;

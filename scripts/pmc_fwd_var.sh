@@ -21,6 +21,8 @@ for p in $passes; do
     e) pass e GRBM_GUI_ACTIVE || exit 1;;
     f) pass f SQ_IFETCH SQ_IFETCH_LEVEL SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_WAVES SQ_INSTS_BRANCH SQ_INSTS_SENDMSG SQ_INSTS_EXP_GDS || pass f SQ_IFETCH SQ_IFETCH_LEVEL SQ_WAVES || exit 1;;
     g) pass g SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE || pass g SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES || exit 1;;
+    h) pass h FETCH_SIZE || exit 1;;
+    i) pass i WRITE_SIZE || exit 1;;
     t1) pass t1 TCP_GATE_EN1 TCP_GATE_EN2 TCP_PENDING_STALL_CYCLES TCP_TOTAL_ACCESSES || exit 1;;
     t2) pass t2 TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_UTCL1_REQUEST TCP_TA_TCP_STATE_READ || exit 1;;
     t3) pass t3 TA_TA_BUSY TA_BUFFER_TOTAL_CYCLES || exit 1;;
