@@ -121,23 +121,14 @@ k_bwd_brick(const float4 *__restrict__ featK, const TO *__restrict__ grad_out, c
     BrickShared<VT> *sh = reinterpret_cast<BrickShared<VT> *>(smem + lds_bytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
 
-    // XCD-aware order (speed only; blocks i, i + 8, ... share an XCD): four tiles per sample, XCDs 0-3 on sample 2 p, XCDs 4-7 on sample 2 p + 1,
-    // as k_fwd_ws (brick_common.h: brick_tiles) -- the bricks an XCD works on at a time share most of their windows.  Against round 4's order
-    // (every XCD an eighth of every sample's brick list): window-fill reads 8.8 -> 6.7 GB, 13.02 -> 12.85 ms (profiles/r05_bwd_ablations.txt E)
-    const int nbx = bricks_per_sample / (nby * nbz);
-    const BrickTiles T = brick_tiles(nbx, nby, nbz);
+    // XCD-aware order (speed only; blocks i, i + 8, ... share an XCD): every XCD takes an eighth of every sample's brick list (an x slab).  The
+    // forward's four-tiles-per-sample order (brick_common.h: brick_tiles) was measured here too: -1 % at the north star (window-fill reads 8.8 ->
+    // 6.7 GB) but +3 % at configs[3] and configs[4], with either order of the bricks inside a tile: not taken (profiles/r05_bwd_ablations.txt E)
+    const int share = (bricks_per_sample + 7) >> 3;
     const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int pj = j / T.share, r = j % T.share, tile = xcd & 3;
-    int b = 2 * pj + (xcd >> 2);
-    if ((2 * pj + 1) * bricks_per_sample >= total_blocks) {                      // an odd batch's last sample: XCD t and t + 4 take alternate bricks of tile t
-        b = 2 * pj;
-        if ((r & 1) != (xcd >> 2)) return;
-    }
-    const int cz = r % T.hz, cy = (r / T.hz) % T.hy, cx = r / (T.hz * T.hy);
-    const int kz = T.split_z ? (tile >> 1) * T.hz + cz : cz;
-    const int kx = T.split_x ? (T.split_z ? tile & 1 : tile >> 1) * T.hx + cx : cx;
-    const int ky = T.split_y ? (tile & 1) * T.hy + cy : cy;
-    if (kx >= nbx || ky >= nby || kz >= nbz || b * bricks_per_sample >= total_blocks) return;
+    const int b = j / share, brick = xcd * share + j % share;
+    if (brick >= bricks_per_sample || b * bricks_per_sample >= total_blocks) return;
+    const int kz = brick % nbz, ky = (brick / nbz) % nby, kx = brick / (nbz * nby);
     const long long N = (long long)X * Y * Z;
     const int HW = H * W, nq = C >> 2, nqv = (C + 3) >> 2;                       // nq: whole channel quads (the quad loop's); nqv: quads per view of the staged copy and the accumulator
 
@@ -615,7 +606,7 @@ hipError_t launch_bv(const float4 *featK, const TO *grad_out, const float *proj,
     auto kern = k_bwd_brick<METHOD, VT, NT, TO, BZ>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
-    const int grid = 8 * brick_tiles(nbx, nby, nbz).share * ((p.B + 1) / 2);       // 8 XCDs x bricks of a tile x pairs of samples
+    const int grid = ((bps + 7) / 8) * 8 * p.B;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), lds, s, featK, grad_out, proj, coords, gradK, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps,
                        lds_bytes, total, p.V, make_gate(p, true));
     return hipGetLastError();
