@@ -49,6 +49,7 @@ constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 template <int VT>
 struct WsWindows {
     int wx0[VT], wy0[VT], ws[VT], whp[VT], slot0[VT], nch[VT + 1];
+    int whr[VT], wbw[VT];        // half-rows / columns that taps can reach (whp is rounded up to 8, the last chunk to 64 slots: the rest is padding)
     bool fits;
 };
 
@@ -65,6 +66,7 @@ __device__ __forceinline__ void ws_size_windows(const FwdShared<VT> *sh, WsWindo
             const int y0w = ymin & ~1;                                           // origin row even: rows split by parity
             int bw = 0, hp = 0;
             if (xmax >= xmin) { bw = xmax - xmin + 2; hp = (ymax + 3 - y0w) >> 1; }   // taps reach x0 + 1, y0 + 1
+            w.whr[v] = hp; w.wbw[v] = bw;
             if (round8) hp = (hp + 7) & ~7;
             const int stride = 2 * hp, chunks = (stride * bw + 63) >> 6;
             w.wx0[v] = xmin; w.wy0[v] = y0w; w.ws[v] = stride; w.whp[v] = hp;
@@ -183,17 +185,21 @@ __device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdSha
             int v = 0;
 #pragma unroll
             for (int uu = 1; uu < VT; ++uu) v += c >= win.nch[uu] ? 1 : 0;
-            int sv = win.ws[0], ox = win.wx0[0], oy = win.wy0[0], c0 = win.nch[0], hv = win.whp[0];
+            int sv = win.ws[0], ox = win.wx0[0], oy = win.wy0[0], c0 = win.nch[0], hv = win.whp[0], hr = win.whr[0], bwv = win.wbw[0];
 #pragma unroll
-            for (int uu = 1; uu < VT; ++uu) if (v == uu) { sv = win.ws[uu]; ox = win.wx0[uu]; oy = win.wy0[uu]; c0 = win.nch[uu]; hv = win.whp[uu]; }
+            for (int uu = 1; uu < VT; ++uu)
+                if (v == uu) { sv = win.ws[uu]; ox = win.wx0[uu]; oy = win.wy0[uu]; c0 = win.nch[uu]; hv = win.whp[uu]; hr = win.whr[uu]; bwv = win.wbw[uu]; }
             const int slot = ((c - c0) << 6) + lane;
             const int px = slot / sv;
             int py = slot - px * sv;
+            // padding -- half-rows past the ones taps can reach (whp is rounded up to 8 for conflict-free tap reads), columns past the window
+            // in the last 64-slot chunk --: never read, so never fetched (bit 0 of the offset: the lane sits out of the LDS-DMA)
+            const bool dead = px >= bwv || (py >= hv ? py - hv : py) >= hr;
             py = py >= hv ? 2 * (py - hv) + 1 : 2 * py;                          // slot inside the column -> row (even rows first)
             int gx = ox + px, gy = oy + py;                                      // pad rows / columns past the window / outside the
             gx = gx < 0 ? 0 : (gx > B.W - 1 ? B.W - 1 : gx);                     // image: clamp -- those slots only meet zero weights
             gy = gy < 0 ? 0 : (gy > B.H - 1 ? B.H - 1 : gy);
-            go[rr] = (unsigned)((v * B.nqv) * HW + gx * B.H + gy) * 16u;
+            go[rr] = (unsigned)((v * B.nqv) * HW + gx * B.H + gy) * 16u | (dead ? 1u : 0u);
             ++n_m;
         }
     }
@@ -201,7 +207,10 @@ __device__ __forceinline__ void ws_memory_role(unsigned char *smem, const FwdSha
     auto dma = [&](int boff) __attribute__((always_inline)) {
 #pragma unroll
         for (int rr = 0; rr < MC; ++rr)
-            if (rr < n_m) glds16_m0(src_n, go[rr], B.lds_base + (unsigned)(boff + kZeroBytes + (wave + rr * NMW) * 1024));
+            if (rr < n_m) {
+                const unsigned dst = B.lds_base + (unsigned)(boff + kZeroBytes + (wave + rr * NMW) * 1024);
+                if (!(go[rr] & 1u)) glds16_m0(src_n, go[rr], dst);                // (lane-divergent: an exec mask around the piece)
+            }
         src_n += HW;
     };
     // ---- stores.  fp32 volume: instruction j = wave + NMW k (k < NS = 32 / NMW) writes channel j >> 3, brick row y = j & 7: lane = (x, z quad)
