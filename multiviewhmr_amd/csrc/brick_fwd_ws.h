@@ -10,14 +10,14 @@
 // A timing build in which 4 of the 16 waves issued every memory instruction and the other 12 only computed ran at the memory floor.
 //
 // Mapping.
-//   block    = one 8 x 8 x 32 brick, 768 threads = 4 MEMORY waves + 8 COMPUTE waves (three waves per SIMD, <= 168 VGPRs);
-//   compute  = wave cw owns the brick's row y = cw: lane = (x parity, z), four voxels per lane (x = parity + 2u).  Tap records
+//   block    = one 8 x 8 x 32 brick, 1 024 threads = 2 MEMORY waves + 14 COMPUTE waves (<= 128 VGPRs; three layouts were built: the kernel's comment);
+//   compute  = a wave owns 2 or 3 "units" (two x-adjacent voxel columns x 32 z: lane = (x parity, z)) of the brick's 32.  Tap records
 //              (two LDS addresses + four weights per voxel and view) live in registers for all C / 4 channel quads.  A job
 //              (quad, voxel) is 16 ds_read_b128 + 64 FMAs + the aggregate; its four results go to the result buffer R in LDS as
 //              four ds_write_b32.  Compute waves never issue a vector-memory instruction;
 //   memory   = per quad: (A) wait for its LDS-DMA pieces of this quad's windows, barrier A (publishes the windows), read last quad's
-//              results from R (8 x ds_read_b128 per wave), barrier B (R is free again), request the next quad's windows
-//              (global_load_lds_dwordx4, pieces wave, wave + 4, ...), store last quad's results (8 x buffer_store_dwordx4 per wave:
+//              results from R (32 x ds_read_b128 over the memory waves), raise the "R is free" counter, request the next quad's windows
+//              (global_load_lds_dwordx4, pieces wave, wave + NMW, ...), store last quad's results (32 x buffer_store_dwordx4 over the memory waves:
 //              one instruction = 8 rows y x 128 B of one channel plane).  These waves spend their time waiting for FIFO room --
 //              that is their job;
 //   LDS      = two window buffers EXACTLY 64 512 B apart (the quad loop is unrolled by two and the second buffer is addressed
@@ -32,10 +32,10 @@
 
 namespace mvhmr {
 
-constexpr int kWsMemWaves = 4;
 #ifndef MVHMR_WS_CFG
-#define MVHMR_WS_CFG 1                                                            // wave layout of k_fwd_ws (see the kernel)
+#define MVHMR_WS_CFG 2                                                            // wave layout of k_fwd_ws (see the kernel)
 #endif
+constexpr int kWsMemWaves = MVHMR_WS_CFG == 2 ? 2 : 4;
 constexpr int kWsBufBytes = 64512;                                   // window buffer: zero region + 3 904 slots; < 65 536: a DS offset
 constexpr int kWsCapSlots = (kWsBufBytes - kZeroBytes) / 16;
 constexpr int kWsResBytes = 4 * 64 * 32 * 4;                         // R[channel][column = x * 8 + y][z] fp32
@@ -511,8 +511,12 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
     }
 }
 
-// CFG 0: 768 threads = 4 memory waves + 8 compute waves of 4 units (<= 168 VGPRs); CFG 1: 1024 threads = 4 memory waves + 8 compute
-// waves of 3 units + 4 of 2 units (<= 128 VGPRs; waves w, w + 4, w + 8, w + 12 share a SIMD, so every SIMD computes 3 + 3 + 2 units)
+// Wave layouts (MVHMR_WS_CFG; waves w, w + 4, w + 8, w + 12 share a SIMD, every SIMD computes 8 units):
+//   0: 768 threads  = 4 memory waves + 8 compute waves of 4 units (<= 168 VGPRs)                                              3.48 ms
+//   1: 1 024 threads = 4 memory waves + 8 compute waves of 3 units + 4 of 2 (every SIMD: 1 memory wave + 3 / 3 / 2 units)     3.21 ms (five same-box pairs)
+//   2: 1 024 threads = 2 memory waves (SIMDs 0, 1: + 3 / 3 / 2 units) + 14 compute waves (SIMDs 2, 3: four waves of 2 units)   3.18 ms  <- shipped
+// (2 against 1: half of the three-unit waves -- the ones whose column strides have to stay in SGPRs, which halves the rate of the two
+// v_add_u32 per voxel, view and quad that use them -- become two-unit waves; two memory waves keep up with 32 LDS-DMA pieces + 16 stores each)
 template <int METHOD, int VT, typename TO, bool PRE, int CFG>
 __global__ void __launch_bounds__(CFG == 0 ? 768 : 1024)
 k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords, TO *__restrict__ out, int C, int H, int W,
@@ -522,7 +526,7 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
     // their samples read kAbsentSample from a slot of the zero region (softmax, max) or plain zeros (sum, mean)
     if (gated_off(gate)) return;
     static_assert(!PRE || METHOD == AGG_SOFTMAX, "only the softmax reads a prescaled copy");
-    constexpr int NMW = kWsMemWaves, NCW = CFG == 0 ? 8 : 12;
+    constexpr int NMW = kWsMemWaves, NCW = CFG == 0 ? 8 : CFG == 1 ? 12 : 14;
     extern __shared__ __align__(16) unsigned char smem[];
     FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + kWsLdsBytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
@@ -566,9 +570,18 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
     const int cw = wave - NMW, ctid = tid - NMW * 64;
     if constexpr (CFG == 0) {
         ws_compute_role<METHOD, VT, TO, PRE, 4>(smem, sh, B, coords, cw * 4, lane, ctid, NCW * 64);
-    } else {
+    } else if constexpr (CFG == 1) {
         if (cw < 8) ws_compute_role<METHOD, VT, TO, PRE, 3>(smem, sh, B, coords, cw * 3, lane, ctid, NCW * 64);
         else ws_compute_role<METHOD, VT, TO, PRE, 2>(smem, sh, B, coords, 24 + (cw - 8) * 2, lane, ctid, NCW * 64);
+    } else {
+        // CFG 2: 2 memory waves (SIMDs 0, 1) + 14 compute waves: SIMDs 0 / 1 hold three compute waves of 3 / 3 / 2 units, SIMDs 2 / 3 four of 2
+        const int simd = wave & 3, idx = wave >> 2;
+        if (simd < 2) {
+            if (idx < 3) ws_compute_role<METHOD, VT, TO, PRE, 3>(smem, sh, B, coords, simd * 8 + (idx - 1) * 3, lane, ctid, NCW * 64);
+            else ws_compute_role<METHOD, VT, TO, PRE, 2>(smem, sh, B, coords, simd * 8 + 6, lane, ctid, NCW * 64);
+        } else {
+            ws_compute_role<METHOD, VT, TO, PRE, 2>(smem, sh, B, coords, simd * 8 + idx * 2, lane, ctid, NCW * 64);
+        }
     }
 }
 
