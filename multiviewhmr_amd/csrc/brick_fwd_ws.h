@@ -364,6 +364,8 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
     // order (even row x0, even row x0 + 1, odd row x0, odd row x0 + 1): for an odd y0 the sum runs sw, se, nw, ne instead of ATen's
     // nw, ne, sw, se -- <= 1 ulp of the sample.
     unsigned ap[NVOX][VT];
+    unsigned aq[NVOX == 2 ? NVOX : 1][VT];                                        // two-unit waves have the registers: the odd-row address on its own (no unpacking)
+    constexpr bool kUnpacked = NVOX == 2;
     int ws16[VT];
     // the column strides: in VGPRs where registers allow (v_add_u32 v, v, v issues at the full rate, v, s, v at half); the three-unit
     // waves of the 1 024-thread layout have none to spare and keep them scalar
@@ -390,7 +392,8 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
                 a0 = kAbsentSlot * 16; a1 = kAbsentSlot * 16;
                 w00[u][v] = 1.f; w01[u][v] = 0.f; w10[u][v] = 0.f; w11[u][v] = 0.f;
             }
-            ap[u][v] = (unsigned)a0 | ((unsigned)a1 << 16);
+            if constexpr (kUnpacked) { ap[u][v] = (unsigned)a0; aq[u][v] = (unsigned)a1; }
+            else ap[u][v] = (unsigned)a0 | ((unsigned)a1 << 16);
         }
     }
     // R address of this lane's unit u0, channel 0: R[channel][column = 2 unit + x parity][z]; unit u0 + u is 256 u bytes further,
@@ -403,7 +406,14 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
         constexpr int BOFF = decltype(boff)::value;
         asm volatile("" : "+v"(ap[u][v]));                                       // unpacked per use: hoisted out of the quad loop, the addresses would spill
         const unsigned pk = ap[u][v];
-        const int base = (int)(pk & 0xFFFFu), base1 = (int)(pk >> 16), far = base + ws16[v], far1 = base1 + ws16[v];
+        int base, base1;
+        if constexpr (kUnpacked) {
+            asm volatile("" : "+v"(aq[u][v]));
+            base = (int)pk; base1 = (int)aq[u][v];
+        } else {
+            base = (int)(pk & 0xFFFFu); base1 = (int)(pk >> 16);
+        }
+        const int far = base + ws16[v], far1 = base1 + ws16[v];
         T[set][0] = lds_tap(smem, base + BOFF); T[set][2] = lds_tap(smem, base1 + BOFF);
         T[set][1] = lds_tap(smem, far + BOFF); T[set][3] = lds_tap(smem, far1 + BOFF);
     };
