@@ -81,40 +81,52 @@ __device__ __forceinline__ void ws_size_windows(const FwdShared<VT> *sh, WsWindo
     w.fits = used <= kWsCapSlots && max_stride + 2 <= kZeroSlots;
 }
 
-// softmax of one channel pair on samples t = log2(e) * s (PRE) or s; weights relative to view 0; da + db comes back for the job's
-// overflow test.  Transcendentals in runs (device_common.h aggregate2).
+// softmax of one channel pair in the form relative to view 0.  s[0] is view 0's sample (log2(e) * s for PRE), s[v] for v >= 1 the DIFFERENCE to
+// it -- folded as such (bilerp_rel: the bilinear sum started from -s[0], one fused operation fewer per view and channel than a sample and a
+// subtraction).  out = s0 + sum(e_v d_v) / (1 + sum e_v), e_v = exp(d_v); PRE: e_v = exp2(d_v), the denominator is accumulated times log2(e)
+// (v_fmamk), so that its reciprocal already carries the ln 2 of the result: 28 instead of 31 operations per channel against the absolute
+// form with its separate scaling.  da + db comes back for the job's overflow test.  Transcendentals in runs (device_common.h aggregate2).
 template <int V, bool PRE>
 __device__ __forceinline__ void ws_softmax_pair(const float (&sa)[V], const float (&sb)[V], float &ra, float &rb, float &dsum)
 {
     float ta[V], tb[V];
 #pragma unroll
     for (int v = 1; v < V; ++v) {
-        ta[v] = PRE ? sa[v] - sa[0] : (sa[v] - sa[0]) * kLog2e;
-        tb[v] = PRE ? sb[v] - sb[0] : (sb[v] - sb[0]) * kLog2e;
+        ta[v] = PRE ? sa[v] : sa[v] * kLog2e;
+        tb[v] = PRE ? sb[v] : sb[v] * kLog2e;
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int v = 1; v < V; ++v) { ta[v] = __builtin_amdgcn_exp2f(ta[v]); tb[v] = __builtin_amdgcn_exp2f(tb[v]); }
     __builtin_amdgcn_sched_barrier(0);
-    float da = 1.f, db = 1.f, na = sa[0], nb = sb[0];
+    float da = PRE ? kLog2e : 1.f, db = da;
+    float na = ta[1] * sa[1], nb = tb[1] * sb[1];
+    if constexpr (PRE) { da = fmaf(ta[1], kLog2e, da); db = fmaf(tb[1], kLog2e, db); }
+    else { da += ta[1]; db += tb[1]; }
 #pragma unroll
-    for (int v = 1; v < V; ++v) {
-        da += ta[v]; na = fmaf(ta[v], sa[v], na);
-        db += tb[v]; nb = fmaf(tb[v], sb[v], nb);
+    for (int v = 2; v < V; ++v) {
+        if constexpr (PRE) { da = fmaf(ta[v], kLog2e, da); db = fmaf(tb[v], kLog2e, db); }
+        else { da += ta[v]; db += tb[v]; }
+        na = fmaf(ta[v], sa[v], na);
+        nb = fmaf(tb[v], sb[v], nb);
     }
     __builtin_amdgcn_sched_barrier(0);
-    float ia = __builtin_amdgcn_rcpf(da), ib = __builtin_amdgcn_rcpf(db);
+    const float ia = __builtin_amdgcn_rcpf(da), ib = __builtin_amdgcn_rcpf(db);   // PRE: ln 2 / (1 + sum e_v)
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (PRE) { ia *= kLn2; ib *= kLn2; }
-    ra = na * ia;
-    rb = nb * ib;
-    dsum = da + db;                                                              // both below 2^60 and no NaN: no e_v reached 2^60, so no e_v * t_v overflowed
+    ra = fmaf(na, ia, PRE ? sa[0] * kLn2 : sa[0]);
+    rb = fmaf(nb, ib, PRE ? sb[0] * kLn2 : sb[0]);
+    dsum = da + db;                                                              // both below 2^60 and no NaN: no e_v reached 2^60, so no e_v * d_v overflowed
 }
 
-// the max form (any finite samples): aggregate<AGG_SOFTMAX> on unscaled samples; on prescaled ones the same with exp2(t - m)
+// the max form (any finite samples whose differences to view 0 are finite): the samples are rebuilt from the relative form; aggregate<AGG_SOFTMAX>
+// on unscaled samples, on prescaled ones the same with exp2(t - m)
 template <int V, bool PRE>
-__device__ __forceinline__ float ws_softmax_safe(const float (&s)[V])
+__device__ __forceinline__ float ws_softmax_safe(const float (&r)[V])
 {
+    float s[V];
+    s[0] = r[0];
+#pragma unroll
+    for (int v = 1; v < V; ++v) s[v] = r[v] + r[0];
     if constexpr (!PRE) {
         return aggregate<AGG_SOFTMAX, V>(s);
     } else {
@@ -130,6 +142,12 @@ __device__ __forceinline__ float ws_softmax_safe(const float (&s)[V])
         }
         return num * (__builtin_amdgcn_rcpf(den) * kLn2);
     }
+}
+
+// the bilinear sum of a view >= 1 relative to view 0's sample s0 (one rounding per step, the last one on the difference itself)
+__device__ __forceinline__ float bilerp_rel(float v00, float v01, float v10, float v11, float w00, float w01, float w10, float w11, float s0)
+{
+    return __fmaf_rn(v11, w11, __fmaf_rn(v10, w10, __fmaf_rn(v01, w01, __fmaf_rn(v00, w00, -s0))));
 }
 
 // ds_write_b32 at an LDS byte address + immediate offset (outside hipcc's lgkmcnt bookkeeping: see write_half)
@@ -291,6 +309,7 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
                                                 int ctid, int cthreads)
 {
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    constexpr bool kRel = METHOD == AGG_SOFTMAX && VT > 1;                       // views >= 1 are folded as differences to view 0 (ws_softmax_pair)
     const int nv = B.nv;
     int dcol, zin;
     fwd_lane_voxel<1>(lane, dcol, zin);                                          // lane = 32 * (x parity) + z (z quads permuted: LDS pass groups are z runs)
@@ -390,7 +409,7 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
             }
             if (kAbsentReads && v >= nv) {                                       // wave-uniform: the absent view's one "tap"
                 a0 = kAbsentSlot * 16; a1 = kAbsentSlot * 16;
-                w00[u][v] = 1.f; w01[u][v] = 0.f; w10[u][v] = 0.f; w11[u][v] = 0.f;
+                w00[u][v] = kRel ? 0.5f : 1.f; w01[u][v] = 0.f; w10[u][v] = 0.f; w11[u][v] = 0.f;   // (relative softmax: -FLT_MAX / 2 - s0 stays finite, so 0 * d is -0, not NaN)
             }
             if constexpr (kUnpacked) { ap[u][v] = (unsigned)a0; aq[u][v] = (unsigned)a1; }
             else ap[u][v] = (unsigned)a0 | ((unsigned)a1 << 16);
@@ -491,7 +510,12 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
                 }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    cur[i][v] = bilerp(T[v & 1][0].v[i], T[v & 1][1].v[i], T[v & 1][2].v[i], T[v & 1][3].v[i], w00[u][v], w01[u][v], w10[u][v], w11[u][v]);
+                    if (kRel && v > 0) {
+                        cur[i][v] = bilerp_rel(T[v & 1][0].v[i], T[v & 1][1].v[i], T[v & 1][2].v[i], T[v & 1][3].v[i], w00[u][v], w01[u][v], w10[u][v], w11[u][v],
+                                               cur[i][0]);
+                    } else {
+                        cur[i][v] = bilerp(T[v & 1][0].v[i], T[v & 1][1].v[i], T[v & 1][2].v[i], T[v & 1][3].v[i], w00[u][v], w01[u][v], w10[u][v], w11[u][v]);
+                    }
                     asm volatile("" : "+v"(cur[i][v]));                           // fold HERE: keeps the tap registers short-lived
                 }
                 __builtin_amdgcn_sched_barrier(0);
