@@ -163,6 +163,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
     TO *const obase = out + (long long)b * C * N + (long long)(q0 * 4) * N;
     const float4 *const fk = featK + (long long)b * nv * nqv * HW + (long long)q0 * HW;
     constexpr bool kAbsentReads = METHOD == AGG_SOFTMAX || METHOD == AGG_MAX;
+    constexpr bool kRel = METHOD == AGG_SOFTMAX;                                  // views >= 1 are folded as differences to view 0 (brick_fwd_kernel.h: ws_softmax_pair)
 
     if (fits) {
         for (int i = tid; i < kZeroSlots * 2; i += NT) {
@@ -191,7 +192,7 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
                 a0[v] = kAbsentSlot * 16;
                 if constexpr (LAY != 0) a1[v] = kAbsentSlot * 16;
                 ws16[v] = 16;
-                w00[v] = 1.f; w01[v] = 0.f; w10[v] = 0.f; w11[v] = 0.f;
+                w00[v] = kRel ? 0.5f : 1.f; w01[v] = 0.f; w10[v] = 0.f; w11[v] = 0.f;   // (relative softmax: -FLT_MAX / 2 - s0 stays finite)
             }
         }
         // ---- DMA chunks of this wave, per group: chunk c covers 64 consecutive slots of one view's window
@@ -308,7 +309,8 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
                     }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        s[i][v] = bilerp(nw.v[i], ne.v[i], sw.v[i], se.v[i], w00[v], w01[v], w10[v], w11[v]);
+                        if (kRel && v > 0) s[i][v] = bilerp_rel(nw.v[i], ne.v[i], sw.v[i], se.v[i], w00[v], w01[v], w10[v], w11[v], s[i][0]);
+                        else s[i][v] = bilerp(nw.v[i], ne.v[i], sw.v[i], se.v[i], w00[v], w01[v], w10[v], w11[v]);
                         asm volatile("" : "+v"(s[i][v]));
                     }
                 }
@@ -316,7 +318,18 @@ k_fwd_brick_groups(const float4 *__restrict__ featK, const float *__restrict__ p
             float res[4];
 #pragma unroll
             for (int i = 0; i < 4; i += 2) {
-                fwd_aggregate2<METHOD, VT>(s[i], s[i + 1], res[i], res[i + 1], (float)nv);
+                if constexpr (kRel) {
+                    // softmax relative to view 0 (ws_softmax_pair: the views >= 1 were folded as differences), overflow test on the denominators,
+                    // the max form as the wave-uniform fallback -- no maximum over the eight views, no subtractions, one exponential fewer
+                    float d;
+                    ws_softmax_pair<VT, false>(s[i], s[i + 1], res[i], res[i + 1], d);
+                    if (__builtin_amdgcn_ballot_w64(!(d < 1.152921504606847e18f)) != 0) {
+                        res[i] = ws_softmax_safe<VT, false>(s[i]);
+                        res[i + 1] = ws_softmax_safe<VT, false>(s[i + 1]);
+                    }
+                } else {
+                    fwd_aggregate2<METHOD, VT>(s[i], s[i + 1], res[i], res[i + 1], (float)nv);
+                }
             }
             store_quad(q, res);
         }

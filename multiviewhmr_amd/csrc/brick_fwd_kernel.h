@@ -112,6 +112,77 @@ __device__ __forceinline__ void fwd_aggregate2(const float (&sa)[VT], const floa
     }
 }
 
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+// softmax of one channel pair in the form relative to view 0.  s[0] is view 0's sample (log2(e) * s for PRE), s[v] for v >= 1 the DIFFERENCE to
+// it -- folded as such (bilerp_rel: the bilinear sum started from -s[0], one fused operation fewer per view and channel than a sample and a
+// subtraction).  out = s0 + sum(e_v d_v) / (1 + sum e_v), e_v = exp(d_v); PRE: e_v = exp2(d_v), the denominator is accumulated times log2(e)
+// (v_fmamk), so that its reciprocal already carries the ln 2 of the result: 28 instead of 31 operations per channel against the absolute
+// form with its separate scaling.  da + db comes back for the job's overflow test.  Transcendentals in runs (device_common.h aggregate2).
+template <int V, bool PRE>
+__device__ __forceinline__ void ws_softmax_pair(const float (&sa)[V], const float (&sb)[V], float &ra, float &rb, float &dsum)
+{
+    float ta[V], tb[V];
+#pragma unroll
+    for (int v = 1; v < V; ++v) {
+        ta[v] = PRE ? sa[v] : sa[v] * kLog2e;
+        tb[v] = PRE ? sb[v] : sb[v] * kLog2e;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int v = 1; v < V; ++v) { ta[v] = __builtin_amdgcn_exp2f(ta[v]); tb[v] = __builtin_amdgcn_exp2f(tb[v]); }
+    __builtin_amdgcn_sched_barrier(0);
+    float da = PRE ? kLog2e : 1.f, db = da;
+    float na = ta[1] * sa[1], nb = tb[1] * sb[1];
+    if constexpr (PRE) { da = fmaf(ta[1], kLog2e, da); db = fmaf(tb[1], kLog2e, db); }
+    else { da += ta[1]; db += tb[1]; }
+#pragma unroll
+    for (int v = 2; v < V; ++v) {
+        if constexpr (PRE) { da = fmaf(ta[v], kLog2e, da); db = fmaf(tb[v], kLog2e, db); }
+        else { da += ta[v]; db += tb[v]; }
+        na = fmaf(ta[v], sa[v], na);
+        nb = fmaf(tb[v], sb[v], nb);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float ia = __builtin_amdgcn_rcpf(da), ib = __builtin_amdgcn_rcpf(db);   // PRE: ln 2 / (1 + sum e_v)
+    __builtin_amdgcn_sched_barrier(0);
+    ra = fmaf(na, ia, PRE ? sa[0] * kLn2 : sa[0]);
+    rb = fmaf(nb, ib, PRE ? sb[0] * kLn2 : sb[0]);
+    dsum = da + db;                                                              // both below 2^60 and no NaN: no e_v reached 2^60, so no e_v * d_v overflowed
+}
+
+// the max form (any finite samples whose differences to view 0 are finite): the samples are rebuilt from the relative form; aggregate<AGG_SOFTMAX>
+// on unscaled samples, on prescaled ones the same with exp2(t - m)
+template <int V, bool PRE>
+__device__ __forceinline__ float ws_softmax_safe(const float (&r)[V])
+{
+    float s[V];
+    s[0] = r[0];
+#pragma unroll
+    for (int v = 1; v < V; ++v) s[v] = r[v] + r[0];
+    if constexpr (!PRE) {
+        return aggregate<AGG_SOFTMAX, V>(s);
+    } else {
+        float m = s[0];
+#pragma unroll
+        for (int v = 1; v < V; ++v) m = vmax(m, s[v]);
+        float den = 0.f, num = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float e = __builtin_amdgcn_exp2f(s[v] - m);
+            den += e;
+            num = fmaf(e, s[v], num);
+        }
+        return num * (__builtin_amdgcn_rcpf(den) * kLn2);
+    }
+}
+
+// the bilinear sum of a view >= 1 relative to view 0's sample s0 (one rounding per step, the last one on the difference itself)
+__device__ __forceinline__ float bilerp_rel(float v00, float v01, float v10, float v11, float w00, float w01, float w10, float w11, float s0)
+{
+    return __fmaf_rn(v11, w11, __fmaf_rn(v10, w10, __fmaf_rn(v01, w01, __fmaf_rn(v00, w00, -s0))));
+}
+
 // s_waitcnt vmcnt(K + n) with an immediate for a wave-uniform n in 0 .. MAXI, tried from the likely end (a wave owns most of its MAXI
 // chunk slots): a handful of scalar compares instead of the 21-way switch of wait_vmcnt
 template <int K, int I, int MAXI>
