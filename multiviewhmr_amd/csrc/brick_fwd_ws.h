@@ -80,11 +80,11 @@ __device__ __forceinline__ void ws_size_windows(const FwdShared<VT> *sh, WsWindo
     w.fits = used <= kWsCapSlots && max_stride + 2 <= kZeroSlots;
 }
 
-// ds_write_b32 at an LDS byte address + immediate offset (outside hipcc's lgkmcnt bookkeeping: see write_half)
-template <int OFF>
-__device__ __forceinline__ void lds_write_at(unsigned addr, float v)
+// two dwords at an LDS byte address + two immediate offsets in units of 256 B (outside hipcc's lgkmcnt bookkeeping: see write_half)
+template <int O0, int O1>
+__device__ __forceinline__ void lds_write2_at(unsigned addr, float v0, float v1)
 {
-    asm volatile("ds_write_b32 %0, %1 offset:%2" : : "v"(addr), "v"(v), "n"(OFF) : "memory");
+    asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(addr), "v"(v0), "v"(v1), "n"(O0), "n"(O1) : "memory");
 }
 
 // what both roles of a block know about their brick
@@ -384,13 +384,14 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
             res[2 * h + 1] = aggregate<METHOD, VT>(s[2 * h + 1]);
         }
     };
-    // two of a job's four results.  ds_write_b32 with the (channel, unit) part of the address in the offset field, written as inline asm:
+    // two of a job's four results.  ds_write2st64_b32 with the (channel, unit) parts of the two addresses in the offset fields, written as inline asm:
     // left to the compiler the twelve addresses become twelve loop-invariant registers.  Outside its lgkmcnt bookkeeping, which is
     // harmless (LDS operations retire in order: an unknown younger write only makes a counted wait cover more); lds_barrier() ends the quad.
     auto write_half = [&](auto utag, auto htag) __attribute__((always_inline)) {
         constexpr int u = decltype(utag)::value, h = decltype(htag)::value;
-        lds_write_at<(2 * h) * 8192 + u * 256>((unsigned)rbase, res[2 * h]);
-        lds_write_at<(2 * h + 1) * 8192 + u * 256>((unsigned)rbase, res[2 * h + 1]);
+        // both channels of the pair in one instruction: ds_write2st64_b32, offsets in units of 256 B (a channel plane of R is 8 192 B = 32 units):
+        // two LDS instructions per job instead of four, -1 % (profiles/r05_fwd_variants.txt)
+        lds_write2_at<(2 * h) * 32 + u, (2 * h + 1) * 32 + u>((unsigned)rbase, res[2 * h], res[2 * h + 1]);
     };
 
     // One quad.  Jobs u = 0 .. NVOX - 1: request views 0 and 1, first half of the PREVIOUS job's aggregate (two results to R), fold view 0 /
