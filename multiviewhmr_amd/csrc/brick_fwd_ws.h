@@ -32,10 +32,7 @@
 
 namespace mvhmr {
 
-#ifndef MVHMR_WS_CFG
-#define MVHMR_WS_CFG 2                                                            // wave layout of k_fwd_ws (see the kernel)
-#endif
-constexpr int kWsMemWaves = MVHMR_WS_CFG == 2 ? 2 : 4;
+constexpr int kWsMemWaves = 2, kWsComputeWaves = 14;                 // the wave layout of k_fwd_ws (see the kernel)
 constexpr int kWsBufBytes = 64512;                                   // window buffer: zero region + 3 904 slots; < 65 536: a DS offset
 constexpr int kWsCapSlots = (kWsBufBytes - kZeroBytes) / 16;
 constexpr int kWsResBytes = 4 * 64 * 32 * 4;                         // R[channel][column = x * 8 + y][z] fp32
@@ -476,14 +473,16 @@ __device__ __forceinline__ void ws_compute_role(unsigned char *smem, FwdShared<V
     }
 }
 
-// Wave layouts (MVHMR_WS_CFG; waves w, w + 4, w + 8, w + 12 share a SIMD, every SIMD computes 8 units):
-//   0: 768 threads  = 4 memory waves + 8 compute waves of 4 units (<= 168 VGPRs)                                              3.48 ms
-//   1: 1 024 threads = 4 memory waves + 8 compute waves of 3 units + 4 of 2 (every SIMD: 1 memory wave + 3 / 3 / 2 units)     3.21 ms (five same-box pairs)
-//   2: 1 024 threads = 2 memory waves (SIMDs 0, 1: + 3 / 3 / 2 units) + 14 compute waves (SIMDs 2, 3: four waves of 2 units)   3.18 ms  <- shipped
-// (2 against 1: half of the three-unit waves -- the ones whose column strides have to stay in SGPRs, which halves the rate of the two
-// v_add_u32 per voxel, view and quad that use them -- become two-unit waves; two memory waves keep up with 32 LDS-DMA pieces + 16 stores each)
-template <int METHOD, int VT, typename TO, bool PRE, int CFG>
-__global__ void __launch_bounds__(CFG == 0 ? 768 : 1024)
+// Wave layout: 1 024 threads = 2 memory waves (waves 0, 1: SIMDs 0, 1) + 14 compute waves; waves w, w + 4, w + 8, w + 12 share a SIMD and every
+// SIMD computes 8 units: SIMDs 0 / 1 three compute waves of 3 / 3 / 2 units, SIMDs 2 / 3 four of 2.  Three layouts were built and timed on one
+// box (scripts/exp/patches/ws_wave_layouts.patch brings the other two back):
+//   768 threads  = 4 memory waves + 8 compute waves of 4 units (<= 168 VGPRs)                                              3.48 ms
+//   1 024 threads = 4 memory waves + 8 compute waves of 3 units + 4 of 2 (every SIMD: 1 memory wave + 3 / 3 / 2 units)     3.21 ms
+//   1 024 threads = 2 memory waves + 14 compute waves (this one)                                                           3.18 ms
+// (half of the three-unit waves -- the ones whose column strides have to stay in SGPRs, which halves the rate of the two v_add_u32 per voxel,
+// view and quad that use them -- became two-unit waves; two memory waves keep up with 32 LDS-DMA pieces + 16 stores each)
+template <int METHOD, int VT, typename TO, bool PRE>
+__global__ void __launch_bounds__(1024)
 k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const Coords coords, TO *__restrict__ out, int C, int H, int W,
          int X, int Y, int Z, int nby, int nbz, int bricks_per_sample, int total_blocks, int nv, Gate gate)
 {
@@ -491,7 +490,7 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
     // their samples read kAbsentSample from a slot of the zero region (softmax, max) or plain zeros (sum, mean)
     if (gated_off(gate)) return;
     static_assert(!PRE || METHOD == AGG_SOFTMAX, "only the softmax reads a prescaled copy");
-    constexpr int NMW = kWsMemWaves, NCW = CFG == 0 ? 8 : CFG == 1 ? 12 : 14;
+    constexpr int NMW = kWsMemWaves, NCW = kWsComputeWaves;
     extern __shared__ __align__(16) unsigned char smem[];
     FwdShared<VT> *sh = reinterpret_cast<FwdShared<VT> *>(smem + kWsLdsBytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = uniform((int)(tid >> 6));
@@ -532,21 +531,13 @@ k_fwd_ws(const float4 *__restrict__ featK, const float *__restrict__ proj, const
         ws_memory_role<VT, TO, NMW>(smem, sh, B, wave, lane);
         return;
     }
-    const int cw = wave - NMW, ctid = tid - NMW * 64;
-    if constexpr (CFG == 0) {
-        ws_compute_role<METHOD, VT, TO, PRE, 4>(smem, sh, B, coords, cw * 4, lane, ctid, NCW * 64);
-    } else if constexpr (CFG == 1) {
-        if (cw < 8) ws_compute_role<METHOD, VT, TO, PRE, 3>(smem, sh, B, coords, cw * 3, lane, ctid, NCW * 64);
-        else ws_compute_role<METHOD, VT, TO, PRE, 2>(smem, sh, B, coords, 24 + (cw - 8) * 2, lane, ctid, NCW * 64);
+    const int ctid = tid - NMW * 64;
+    const int simd = wave & 3, idx = wave >> 2;
+    if (simd < 2) {
+        if (idx < 3) ws_compute_role<METHOD, VT, TO, PRE, 3>(smem, sh, B, coords, simd * 8 + (idx - 1) * 3, lane, ctid, NCW * 64);
+        else ws_compute_role<METHOD, VT, TO, PRE, 2>(smem, sh, B, coords, simd * 8 + 6, lane, ctid, NCW * 64);
     } else {
-        // CFG 2: 2 memory waves (SIMDs 0, 1) + 14 compute waves: SIMDs 0 / 1 hold three compute waves of 3 / 3 / 2 units, SIMDs 2 / 3 four of 2
-        const int simd = wave & 3, idx = wave >> 2;
-        if (simd < 2) {
-            if (idx < 3) ws_compute_role<METHOD, VT, TO, PRE, 3>(smem, sh, B, coords, simd * 8 + (idx - 1) * 3, lane, ctid, NCW * 64);
-            else ws_compute_role<METHOD, VT, TO, PRE, 2>(smem, sh, B, coords, simd * 8 + 6, lane, ctid, NCW * 64);
-        } else {
-            ws_compute_role<METHOD, VT, TO, PRE, 2>(smem, sh, B, coords, simd * 8 + idx * 2, lane, ctid, NCW * 64);
-        }
+        ws_compute_role<METHOD, VT, TO, PRE, 2>(smem, sh, B, coords, simd * 8 + idx * 2, lane, ctid, NCW * 64);
     }
 }
 
@@ -567,12 +558,11 @@ hipError_t launch_fwd_ws_instance(const float4 *featK, const float *proj, const 
     const int bps = nbx * nby * nbz, total = bps * p.B;
     static_assert(sizeof(FwdShared<VT>) <= 1024 && kWsSyncOff + 16 <= 160 * 1024, "LDS layout");
     const size_t lds = (size_t)kWsSyncOff + 16;
-    constexpr int CFG = MVHMR_WS_CFG;
-    auto kern = k_fwd_ws<METHOD, VT, TO, PRE, CFG>;
+    auto kern = k_fwd_ws<METHOD, VT, TO, PRE>;
     hipError_t e = allow_dynamic_lds(reinterpret_cast<const void *>(kern), lds);
     if (e != hipSuccess) return e;
     const int grid = 8 * brick_tiles(nbx, nby, nbz).share * ((p.B + 1) / 2);          // 8 XCDs x bricks of a tile x pairs of samples
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(CFG == 0 ? 768 : 1024), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, total, p.V,
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, featK, proj, coords, out, p.C, p.H, p.W, p.X, p.Y, p.Z, nby, nbz, bps, total, p.V,
                        make_gate(p, true));
     return hipGetLastError();
 }
